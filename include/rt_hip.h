@@ -1,0 +1,171 @@
+/* rt_hip.h -- C ABI of librt_hip.so, the MI355X (gfx950) render path for mkagie/ray_tracing scenes.
+ *
+ * The reference has no FFI of its own: its render path is the inline loop of src/main.rs:531-599,
+ * which owns a tree of Box<dyn Hittable> and calls Ray::get_color (src/lib.rs:56-77) per sample.
+ * Trait objects cannot cross to a GPU, so the boundary is cut in two places:
+ *
+ *   1. Scene construction ("rtb_*"): one entry point per constructor of the reference's prelude
+ *      (src/lib.rs:23-35).  A Rust-side `flatten(&self, b: *mut RtBuilder) -> RtObj` method beside
+ *      Hittable::try_hit (src/objects.rs:16-22) would call these while walking the tree.
+ *   2. Rendering ("rt_*"): replaces the pixel/sample loop and everything below it
+ *      (src/main.rs:567-599): inputs are the flattened world, the camera and the frame
+ *      parameters; output is the per-pixel colour SUM that src/main.rs:585-589 computes.
+ *
+ * All functions return RT_OK (0) or a negative RtStatus; rt_last_error() gives the message of the
+ * calling thread's last failure (the reference panics instead: src/main.rs:511-512, bvh.rs:140).
+ * Nothing unwinds across this boundary.  Handles are opaque; inputs are copied; outputs are
+ * caller-allocated.  Plain C, no HIP or torch types in any signature. */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum RtStatus {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,     /* bad argument / handle */
+    RT_ERR_HIP = -2,         /* a HIP runtime call failed (message has the HIP error string) */
+    RT_ERR_NO_DEVICE = -3,   /* no usable GPU */
+    RT_ERR_OOM = -4,
+    RT_ERR_NO_BBOX = -5,     /* "No bounding box in bvh constructor", src/bvh.rs:140,152,201 */
+    RT_ERR_UNSUPPORTED = -6, /* a tree the flat form cannot express */
+    RT_ERR_CONFIG = -7       /* "Could not open config file." / "Could not read values.", src/main.rs:511-512 */
+} RtStatus;
+
+typedef struct RtBuilder RtBuilder; /* host scene graph under construction */
+typedef struct RtScene RtScene;     /* flattened scene resident on one GPU */
+typedef int32_t RtTex;              /* handles into a builder; < 0 = error */
+typedef int32_t RtMat;
+typedef int32_t RtObj;
+
+const char* rt_last_error(void);
+int rt_device_count(int* count);
+
+/* ------------------------------------------------------------------ scene construction */
+int rtb_create(RtBuilder** out);
+void rtb_destroy(RtBuilder* b);
+int rtb_object_count(const RtBuilder* b);   /* prims + media created so far (= next object id) */
+
+/* textures -- src/textures.rs */
+RtTex rtb_solid_color(RtBuilder* b, double r, double g, double bl);                 /* SolidColor::new  :24 */
+RtTex rtb_checker(RtBuilder* b, RtTex even, RtTex odd);                             /* Checker::new     :40 */
+/* Noise::new :80 -- the caller passes the Perlin tables it drew (:110-128): 256 xyz vectors and
+ * perm_x|perm_y|perm_z (3 x 256 values in 0..255). */
+RtTex rtb_noise(RtBuilder* b, double scale, const double* ranvec_768, const int32_t* perm_768);
+/* materials -- src/materials.rs */
+RtMat rtb_lambertian(RtBuilder* b, RtTex albedo);                                   /* Lambertian::from_texture :67 */
+RtMat rtb_metal(RtBuilder* b, double r, double g, double bl, double fuzz);          /* Metal::new       :116 */
+RtMat rtb_dielectric(RtBuilder* b, double ir);                                      /* Dielectric::new  :164 */
+RtMat rtb_diffuse_light(RtBuilder* b, RtTex emit);                                  /* DiffuseLight::new :230 */
+RtMat rtb_isotropic(RtBuilder* b, RtTex albedo);                                    /* Isotropic::new   :263 */
+/* objects -- src/objects.rs, src/transrot.rs, src/mediums.rs, src/bvh.rs */
+RtObj rtb_sphere(RtBuilder* b, const double center[3], double radius, RtMat m);     /* Sphere::new      :161 */
+RtObj rtb_moving_sphere(RtBuilder* b, const double c0[3], const double c1[3], double t0, double t1, double radius,
+                        RtMat m);                                                   /* MovingSphere::new :266 */
+/* Rectangle::new :363 -- type 0 = Xy, 1 = Xz, 2 = Yz (:339-343) */
+RtObj rtb_rectangle(RtBuilder* b, RtMat m, double x0, double x1, double y0, double y1, double k, int type);
+RtObj rtb_box(RtBuilder* b, const double box_min[3], const double box_max[3], RtMat m);      /* BoxObj::new :442 */
+RtObj rtb_list(RtBuilder* b, const RtObj* children, int n);                         /* HittableList     :25 */
+RtObj rtb_bvh_node(RtBuilder* b, RtObj list, double time0, double time1);           /* BvhNode::new     bvh.rs:89 */
+RtObj rtb_translate(RtBuilder* b, RtObj obj, const double offset[3]);               /* Translate::new   transrot.rs:15 */
+RtObj rtb_rotate_y(RtBuilder* b, RtObj obj, double angle_deg);                      /* RotateY::new     transrot.rs:53 */
+RtObj rtb_constant_medium(RtBuilder* b, RtObj boundary, double density, RtTex albedo);       /* ConstantMedium::new mediums.rs:23 */
+
+/* ------------------------------------------------------------------ host side of main.rs
+ * (what the Rust binary does before the render loop; provided in C++ because no Rust toolchain
+ * exists where this library is built) */
+typedef struct RtConfig {                       /* Config, src/main.rs:453-467 */
+    int32_t image_width, image_height, samples_per_pixel, max_depth;
+    double look_from[3], look_at[3], v_up[3];   /* CameraConfig, src/cameras.rs:10-18 */
+    double vertical_fov_deg, aspect_ratio, aperture, focus_distance;
+    char scene_type[32];                        /* enum Scene tag, src/main.rs:483-494 */
+    int32_t n_list_objects;
+} RtConfig;
+/* Reads a config file (src/main.rs:510-516) and builds its scene (src/main.rs:520-529) into `b`;
+ * `scene_seed` seeds the stream that replaces thread_rng in the canned scenes.  *world receives the
+ * HittableList that main.rs:531 would wrap in BvhNode::new. */
+int rt_config_load(const char* path, RtConfig* out);
+int rt_config_build_scene(const char* path, uint64_t scene_seed, RtBuilder* b, RtObj* world);
+/* One of Random | TwoSpheres | TwoPerlinSpheres | SimpleLight | Cornell | CornellSmoke | FinalScene */
+int rt_canned_scene(RtBuilder* b, const char* scene_type, uint64_t scene_seed, RtObj* world);
+
+/* ------------------------------------------------------------------ flattened scene */
+/* Flattens the tree under `world` (BVH build included, replacing BvhNode::new of src/main.rs:531)
+ * and uploads it to GPU `device`. */
+int rt_scene_create(const RtBuilder* b, RtObj world, int device, RtScene** out);
+void rt_scene_destroy(RtScene* s);
+typedef struct RtSceneInfo {
+    int32_t n_nodes, n_spheres, n_moving_spheres, n_rects, n_instances, n_media, n_materials, n_textures, n_perlin;
+    int32_t tlas_depth, blas_depth, max_stack, n_objects, device;
+    double world_box[6];
+    uint64_t device_bytes;
+} RtSceneInfo;
+int rt_scene_info(const RtScene* s, RtSceneInfo* out);
+/* Host-only flatten (no GPU touched): for inspection and CPU-side checks.  The returned pointer is
+ * an RtSceneView (ray_tracing_amd/csrc/rt_types.h) with HOST pointers, valid until rt_flat_destroy. */
+typedef struct RtFlat RtFlat;
+int rt_flat_create(const RtBuilder* b, RtObj world, RtFlat** out);
+const void* rt_flat_view(const RtFlat* f);
+int rt_flat_info(const RtFlat* f, RtSceneInfo* out);
+void rt_flat_destroy(RtFlat* f);
+
+/* ------------------------------------------------------------------ rendering */
+typedef struct RtCamera {                       /* arguments of Camera::new, src/cameras.rs:38-48 */
+    double look_from[3], look_at[3], v_up[3];
+    double vertical_fov_deg, aspect_ratio, aperture, focus_dist, shutter_open, shutter_close;
+} RtCamera;
+typedef struct RtRenderParams {
+    int32_t width, height;      /* src/main.rs:515-516 */
+    int32_t spp;                /* samples traced by this call (src/main.rs:570) */
+    int32_t sample_offset;      /* absolute index of the first sample: shards of one image use disjoint ranges */
+    int32_t max_depth;          /* src/main.rs:580 */
+    float background[3];        /* src/main.rs:534 (black in the reference) */
+    uint64_t seed;              /* Philox key; (pixel, sample, bounce) is the counter */
+    int32_t paths_per_pass;     /* 0 = default; paths in flight per wavefront pass */
+    int32_t flags;              /* RT_FLAG_* */
+} RtRenderParams;
+#define RT_FLAG_SUMSQ 1         /* also accumulate per-channel sum of squares (accum_sq must be given) */
+
+typedef struct RtStats {
+    uint64_t rays;              /* ray segments = executions of src/lib.rs:63 */
+    uint64_t paths;             /* width * height * spp */
+    uint64_t rays_per_bounce[64]; /* [b-1] = segments traced at bounce b (clamped to 64 entries) */
+    double seconds;             /* wall time inside the call (device work, synchronised) */
+    double kernel_ms_extend;    /* summed device time of the closest-hit + scatter kernel (HIP events) */
+    uint64_t extend_launches;
+    int32_t passes;
+} RtStats;
+
+/* Renders `spp` samples of every pixel and ADDS the per-pixel colour sums (src/main.rs:585-589) to
+ * accum_rgb[H][W][3] (row 0 = top image row, as out_image.put_pixel writes it, src/main.rs:592-597).
+ * rt_render: host buffers (accum_sq may be NULL).  rt_render_device: device buffers on the scene's
+ * GPU, work enqueued on `hip_stream` (a hipStream_t, NULL = default stream) and synchronised
+ * before returning so that `stats` is complete. */
+int rt_render(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* accum_rgb, float* accum_sq, RtStats* stats);
+int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* d_accum_rgb, float* d_accum_sq,
+                     void* hip_stream, RtStats* stats);
+
+/* Parity hook: closest hit of sample `sample` of every pixel (camera ray + src/lib.rs:63).
+ * object_id = creation-order id of the primitive / medium hit, -1 on a miss; t = +inf on a miss.
+ * normal (3 per pixel), front_face and uv (2 per pixel) may be NULL. */
+int rt_trace_primary(RtScene* s, const RtCamera* cam, const RtRenderParams* p, int32_t sample, int32_t* object_id, float* t,
+                     float* normal, int32_t* front_face, float* uv);
+/* Parity hook: one scatter event (src/lib.rs:63-65) for n rays given explicitly.  rays: 7 floats
+ * each (origin, direction, time); pixel/sample/bounce select the Philox draws of ray i as
+ * (pixel0 + i, sample, bounce).  out: 14 floats per ray = status (-1 miss, 0 absorbed, 1 scattered),
+ * emitted rgb, attenuation rgb, scattered origin, direction, time. */
+int rt_scatter_rays(RtScene* s, const float* rays, int32_t n, uint32_t pixel0, uint32_t sample, int32_t bounce, uint64_t seed,
+                    float* out);
+
+/* src/utils.rs:49-63: 256 * clamp(sqrt(sum / spp), 0, 0.999) -> u8, on the host. */
+int rt_tonemap_u8(const float* accum_rgb, int32_t n_pixels, int32_t spp, uint8_t* rgb);
+/* Writes a binary PPM (P6) of the tonemapped image. */
+int rt_write_ppm(const char* path, const uint8_t* rgb, int32_t width, int32_t height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

@@ -1,0 +1,52 @@
+"""Builds librt_hip.so (HIP kernels + C++ host + C ABI) and rt_cli for gfx950, in-tree.
+
+hipcc cross-compiles without a GPU, so this runs anywhere the ROCm toolchain is installed.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librt_hip.so")
+CLI = os.path.join(HERE, "rt_cli")
+SOURCES = ["render.hip", "capi.cpp", "scene_builder.cpp", "flatten.cpp", "config.cpp"]
+HEADERS = ["rt_types.h", "rt_device.h", "scene_builder.h", "capi_internal.h", "../../include/rt_hip.h"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the ROCm toolchain is required to build librt_hip.so")
+    return exe
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = _hipcc()
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    if force or _stale(LIB, srcs + hdrs + [os.path.abspath(__file__)]):
+        cmd = [hipcc] + FLAGS + ["-shared", "-o", LIB] + srcs
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    cli_src = os.path.join(CSRC, "rt_cli.cpp")
+    if force or _stale(CLI, [cli_src, LIB]):
+        cmd = [hipcc, "-O2", "-std=c++17", "-o", CLI, cli_src, "-L" + HERE, "-lrt_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

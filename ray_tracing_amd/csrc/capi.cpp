@@ -1,0 +1,145 @@
+// capi.cpp -- the host-only half of include/rt_hip.h: builder entry points (one per reference
+// constructor), config loading, host flatten, tonemap and PPM output.  No HIP calls here.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include "capi_internal.h"
+
+thread_local std::string g_rt_error;
+int rt_set_error(int code, const std::string& msg) { g_rt_error = msg; return code; }
+
+static rt::Vec3 v3d(const double* p) { return rt::vec3(p[0], p[1], p[2]); }
+static int handle(RtBuilder* b, int h) { if (h < 0) g_rt_error = b->b.error; return h; }
+#define NEED(b) do { if (!(b)) return rt_set_error(RT_ERR_INVALID, "null builder"); } while (0)
+
+static int status_of(const std::string& msg) {
+    if (msg.find("No bounding box") != std::string::npos) return RT_ERR_NO_BBOX;
+    if (msg.find("flatten:") != std::string::npos) return RT_ERR_UNSUPPORTED;
+    return RT_ERR_INVALID;
+}
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_rt_error.c_str(); }
+
+int rtb_create(RtBuilder** out) {
+    if (!out) return rt_set_error(RT_ERR_INVALID, "null argument");
+    *out = new RtBuilder;
+    return RT_OK;
+}
+void rtb_destroy(RtBuilder* b) { delete b; }
+int rtb_object_count(const RtBuilder* b) { return b ? b->b.next_id : 0; }
+
+RtTex rtb_solid_color(RtBuilder* b, double r, double g, double bl) { NEED(b); return handle(b, b->b.solid_color(rt::vec3(r, g, bl))); }
+RtTex rtb_checker(RtBuilder* b, RtTex even, RtTex odd) { NEED(b); return handle(b, b->b.checker(even, odd)); }
+RtTex rtb_noise(RtBuilder* b, double scale, const double* ranvec, const int32_t* perm) {
+    NEED(b);
+    if (!ranvec || !perm) return rt_set_error(RT_ERR_INVALID, "rtb_noise: null table");
+    rt::PerlinTable t;
+    for (int i = 0; i < 256; ++i) for (int c = 0; c < 3; ++c) t.ranvec[i][c] = ranvec[3 * i + c];
+    for (int k = 0; k < 3; ++k) for (int i = 0; i < 256; ++i) {
+        int32_t v = perm[k * 256 + i];
+        if (v < 0 || v > 255) return rt_set_error(RT_ERR_INVALID, "rtb_noise: permutation entry outside 0..255");
+        t.perm[k][i] = v;
+    }
+    return handle(b, b->b.noise_from_table(scale, t));
+}
+RtMat rtb_lambertian(RtBuilder* b, RtTex albedo) { NEED(b); return handle(b, b->b.lambertian_from_texture(albedo)); }
+RtMat rtb_metal(RtBuilder* b, double r, double g, double bl, double fuzz) { NEED(b); return handle(b, b->b.metal(rt::vec3(r, g, bl), fuzz)); }
+RtMat rtb_dielectric(RtBuilder* b, double ir) { NEED(b); return handle(b, b->b.dielectric(ir)); }
+RtMat rtb_diffuse_light(RtBuilder* b, RtTex emit) { NEED(b); return handle(b, b->b.diffuse_light(emit)); }
+RtMat rtb_isotropic(RtBuilder* b, RtTex albedo) { NEED(b); return handle(b, b->b.isotropic(albedo)); }
+
+RtObj rtb_sphere(RtBuilder* b, const double c[3], double r, RtMat m) { NEED(b); if (!c) return rt_set_error(RT_ERR_INVALID, "null center"); return handle(b, b->b.sphere(v3d(c), r, m)); }
+RtObj rtb_moving_sphere(RtBuilder* b, const double c0[3], const double c1[3], double t0, double t1, double r, RtMat m) {
+    NEED(b); if (!c0 || !c1) return rt_set_error(RT_ERR_INVALID, "null center");
+    return handle(b, b->b.moving_sphere(v3d(c0), v3d(c1), t0, t1, r, m));
+}
+RtObj rtb_rectangle(RtBuilder* b, RtMat m, double x0, double x1, double y0, double y1, double k, int type) {
+    NEED(b); if (type < 0 || type > 2) return rt_set_error(RT_ERR_INVALID, "rectangle type must be 0 (Xy), 1 (Xz) or 2 (Yz)");
+    return handle(b, b->b.rectangle(m, x0, x1, y0, y1, k, (rt::RectangleType)type));
+}
+RtObj rtb_box(RtBuilder* b, const double mn[3], const double mx[3], RtMat m) { NEED(b); if (!mn || !mx) return rt_set_error(RT_ERR_INVALID, "null corner"); return handle(b, b->b.box(v3d(mn), v3d(mx), m)); }
+RtObj rtb_list(RtBuilder* b, const RtObj* ch, int n) {
+    NEED(b); if (n < 0 || (n > 0 && !ch)) return rt_set_error(RT_ERR_INVALID, "bad child array");
+    return handle(b, b->b.list(std::vector<int>(ch, ch + n)));
+}
+RtObj rtb_bvh_node(RtBuilder* b, RtObj l, double t0, double t1) { NEED(b); return handle(b, b->b.bvh_node(l, t0, t1)); }
+RtObj rtb_translate(RtBuilder* b, RtObj o, const double off[3]) { NEED(b); if (!off) return rt_set_error(RT_ERR_INVALID, "null offset"); return handle(b, b->b.translate(o, v3d(off))); }
+RtObj rtb_rotate_y(RtBuilder* b, RtObj o, double deg) { NEED(b); return handle(b, b->b.rotate_y(o, deg)); }
+RtObj rtb_constant_medium(RtBuilder* b, RtObj boundary, double density, RtTex albedo) { NEED(b); return handle(b, b->b.constant_medium(boundary, density, albedo)); }
+
+// ------------------------------------------------------------------ config / canned scenes
+static void fill_config(const rt::Config& c, RtConfig* o) {
+    std::memset(o, 0, sizeof(*o));
+    o->image_width = c.image_width; o->image_height = c.image_height(); o->samples_per_pixel = c.samples_per_pixel; o->max_depth = c.max_depth;
+    const rt::Vec3* src[3] = {&c.camera.look_from, &c.camera.look_at, &c.camera.v_up};
+    double* dst[3] = {o->look_from, o->look_at, o->v_up};
+    for (int i = 0; i < 3; ++i) { dst[i][0] = src[i]->x; dst[i][1] = src[i]->y; dst[i][2] = src[i]->z; }
+    o->vertical_fov_deg = c.camera.vertical_fov_deg; o->aspect_ratio = c.camera.aspect_ratio; o->aperture = c.camera.aperture;
+    o->focus_distance = c.camera.focus_distance;
+    std::snprintf(o->scene_type, sizeof(o->scene_type), "%s", c.scene_type.c_str());
+    o->n_list_objects = (int32_t)c.objects.size();
+}
+int rt_config_load(const char* path, RtConfig* out) {
+    if (!path || !out) return rt_set_error(RT_ERR_INVALID, "null argument");
+    rt::Config c; std::string err;
+    if (!rt::load_config(path, c, err)) return rt_set_error(RT_ERR_CONFIG, err);
+    fill_config(c, out);
+    return RT_OK;
+}
+int rt_config_build_scene(const char* path, uint64_t seed, RtBuilder* b, RtObj* world) {
+    if (!path || !b || !world) return rt_set_error(RT_ERR_INVALID, "null argument");
+    rt::Config c; std::string err;
+    if (!rt::load_config(path, c, err)) return rt_set_error(RT_ERR_CONFIG, err);
+    int w = rt::scene_from_config(b->b, c, seed);
+    if (w < 0) return rt_set_error(RT_ERR_CONFIG, b->b.error);
+    *world = w;
+    return RT_OK;
+}
+int rt_canned_scene(RtBuilder* b, const char* type, uint64_t seed, RtObj* world) {
+    if (!b || !type || !world) return rt_set_error(RT_ERR_INVALID, "null argument");
+    int w = rt::canned_scene(b->b, type, seed);
+    if (w < 0) return rt_set_error(RT_ERR_CONFIG, b->b.error);
+    *world = w;
+    return RT_OK;
+}
+
+// ------------------------------------------------------------------ host flatten
+int rt_flat_create(const RtBuilder* b, RtObj world, RtFlat** out) {
+    if (!b || !out) return rt_set_error(RT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    RtFlat* f = new RtFlat;
+    std::string err;
+    if (!rt::flatten(b->b, world, f->flat, err)) { delete f; return rt_set_error(status_of(err), err); }
+    f->view = f->flat.view();
+    *out = f;
+    return RT_OK;
+}
+const void* rt_flat_view(const RtFlat* f) { return f ? &f->view : nullptr; }
+void rt_flat_destroy(RtFlat* f) { delete f; }
+
+// ------------------------------------------------------------------ output (utils.rs:49-63)
+int rt_tonemap_u8(const float* accum, int32_t n_pixels, int32_t spp, uint8_t* rgb) {
+    if (!accum || !rgb || n_pixels < 0 || spp <= 0) return rt_set_error(RT_ERR_INVALID, "bad argument");
+    double scale = 1.0 / (double)spp;
+    for (size_t i = 0; i < (size_t)n_pixels * 3; ++i) {
+        double v = std::sqrt(scale * (double)accum[i]);  // gamma 2
+        v = std::max(std::min(v, 0.999), 0.0);           // NaN -> 0 like Rust's f64::min/max + `as u8`
+        if (!(v == v)) v = 0.0;
+        rgb[i] = (uint8_t)(256.0 * v);
+    }
+    return RT_OK;
+}
+int rt_write_ppm(const char* path, const uint8_t* rgb, int32_t w, int32_t h) {
+    if (!path || !rgb || w <= 0 || h <= 0) return rt_set_error(RT_ERR_INVALID, "bad argument");
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return rt_set_error(RT_ERR_INVALID, std::string("cannot open ") + path);
+    std::fprintf(f, "P6\n%d %d\n255\n", w, h);
+    size_t n = (size_t)w * h * 3, wr = std::fwrite(rgb, 1, n, f);
+    std::fclose(f);
+    return wr == n ? RT_OK : rt_set_error(RT_ERR_INVALID, "short write");
+}
+
+}  // extern "C"

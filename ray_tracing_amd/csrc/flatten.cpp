@@ -1,0 +1,390 @@
+// flatten.cpp -- turns the Builder's object tree into the flat arrays of rt_types.h.
+//
+// The reference traverses a pointer tree (BvhNode -> Box<dyn Hittable>, bvh.rs:159-187) in which
+// HittableList / BoxObj / nested BvhNode are only grouping devices: the closest hit does not depend
+// on them.  The flattener therefore dissolves all grouping, keeps every primitive with the chain of
+// Translate / RotateY wrappers above it (transrot.rs), and builds
+//   * one bottom-level BVH per distinct chain, over that chain's primitives in object space,
+//   * a top-level BVH over the untransformed primitives and the instances,
+// with a binned-SAH builder instead of the reference's random-axis median split (bvh.rs:96-122).
+// Constant media (mediums.rs) are kept out of the BVH: each becomes a record holding its boundary
+// primitives, which the kernels test after the surface hit is known.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include "scene_builder.h"
+
+namespace rt {
+namespace {
+
+const double kInf = std::numeric_limits<double>::infinity();
+
+struct Box3 {
+    double mn[3], mx[3];
+    Box3() { for (int a = 0; a < 3; ++a) { mn[a] = kInf; mx[a] = -kInf; } }
+    void grow(const Box3& o) { for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], o.mn[a]); mx[a] = std::max(mx[a], o.mx[a]); } }
+    void grow_pt(double x, double y, double z) {
+        double p[3] = {x, y, z};
+        for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], p[a]); mx[a] = std::max(mx[a], p[a]); }
+    }
+    double area() const {
+        double d[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+        if (d[0] < 0 || d[1] < 0 || d[2] < 0) return 0.0;
+        return 2.0 * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
+    }
+    bool valid() const { return mn[0] <= mx[0] && mn[1] <= mx[1] && mn[2] <= mx[2]; }
+};
+
+struct Op { int type; double a, b, c; };  // translate: offset xyz | rotate_y: cos, sin
+struct PrimRef { int obj; int chain; };
+struct MediumRef { int obj; int chain; std::vector<PrimRef> boundary; };
+struct Item { Box3 box; double cen[3]; int cls; int ref; };  // cls 0..2 = primitive kind, 3 = instance
+
+float f_down(double v) { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity()); return f; }
+float f_up(double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity()); return f; }
+float i2f(int32_t i) { float f; std::memcpy(&f, &i, 4); return f; }
+rt_f4 f4(float x, float y, float z, float w) { rt_f4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+int ceil_log2(size_t n) { int l = 0; while (((size_t)1 << l) < n) ++l; return l; }
+
+class Flattener {
+public:
+    Flattener(const Builder& b_, FlatScene& out_, std::string& err_) : b(b_), out(out_), err(err_) {}
+
+    bool run(HittableObj world) {
+        if (!b.valid_obj(world)) return fail("flatten: bad world handle");
+        chains.push_back(std::vector<Op>());
+        chain_prims.push_back(std::vector<PrimRef>());
+        if (!walk(world, 0, nullptr, 0)) return false;
+        out = FlatScene();
+        out.n_ids = b.next_id;
+        emit_tables();
+
+        // Boundary primitives of the media first (they are never referenced by the BVH).
+        for (MediumRef& m : media) if (!emit_medium(m)) return false;
+
+        // One bottom-level BVH + instance record per non-empty transformed chain.
+        std::vector<Item> top;
+        int max_blas = 0;
+        for (size_t c = 1; c < chains.size(); ++c) {
+            if (chain_prims[c].empty()) continue;
+            std::vector<Item> items;
+            for (const PrimRef& p : chain_prims[c]) items.push_back(prim_item(p));
+            int depth = 0;
+            int root = build_root(items, kBlasBudget, depth);
+            max_blas = std::max(max_blas, depth);
+            Box3 wb = chain_world_box(node_box(root), chains[c]);
+            Item it; it.box = wb; it.cls = 3; it.ref = emit_instance((int)c, root);
+            for (int a = 0; a < 3; ++a) it.cen[a] = 0.5 * (wb.mn[a] + wb.mx[a]);
+            top.push_back(it);
+        }
+        for (const PrimRef& p : chain_prims[0]) top.push_back(prim_item(p));
+        out.blas_depth = max_blas;
+        if (!top.empty()) {
+            int budget = RT_STACK_DEPTH - 2 - (out.instances.empty() ? 0 : max_blas + 1);
+            if (budget < 4) return fail("flatten: instance BVH too deep for the traversal stack");
+            int depth = 0;
+            out.root = build_root(top, budget, depth);
+            out.tlas_depth = depth;
+            Box3 wb = node_box(out.root);
+            for (int a = 0; a < 3; ++a) { out.world_box[a] = wb.mn[a]; out.world_box[3 + a] = wb.mx[a]; }
+        }
+        out.max_stack = out.tlas_depth + (out.instances.empty() ? 0 : 1 + max_blas);
+        if (out.max_stack > RT_STACK_DEPTH) return fail("flatten: BVH deeper than the traversal stack");
+        if (!err.empty()) return false;
+        return true;
+    }
+
+private:
+    static const int kBlasBudget = 18;
+    const Builder& b; FlatScene& out; std::string& err;
+    std::vector<std::vector<Op>> chains;
+    std::vector<std::vector<PrimRef>> chain_prims;
+    std::vector<MediumRef> media;
+    std::vector<int> chain_instance;  // chain -> instance index (for media boundaries), -1 if none yet
+
+    bool fail(const std::string& m) { err = m; return false; }
+
+    // ---- tree walk (dissolves grouping, accumulates transform chains)
+    bool walk(int oi, int chain, std::vector<PrimRef>* sink, int depth) {
+        if (depth > 4096) return fail("flatten: object graph too deep (cycle?)");
+        const ObjNode& o = b.objects[oi];
+        switch (o.type) {
+        case OBJ_SPHERE: case OBJ_MSPHERE: case OBJ_RECT: {
+            PrimRef p = {oi, chain};
+            if (sink) sink->push_back(p); else chain_prims[chain].push_back(p);
+            return true;
+        }
+        case OBJ_BOX: case OBJ_LIST: case OBJ_BVH:
+            for (int c : o.children) if (!walk(c, chain, sink, depth + 1)) return false;
+            return true;
+        case OBJ_TRANSLATE: case OBJ_ROTATE_Y: {
+            std::vector<Op> ops = chains[chain];
+            Op op; op.type = o.type == OBJ_TRANSLATE ? RT_OP_TRANSLATE : RT_OP_ROTATE_Y;
+            if (o.type == OBJ_TRANSLATE) { op.a = o.p[0]; op.b = o.p[1]; op.c = o.p[2]; }
+            else { op.a = o.p[2]; op.b = o.p[1]; op.c = 0; }  // cos, sin
+            ops.push_back(op);
+            chains.push_back(ops); chain_prims.push_back(std::vector<PrimRef>());
+            return walk(o.children[0], (int)chains.size() - 1, sink, depth + 1);
+        }
+        case OBJ_MEDIUM: {
+            if (sink) return fail("flatten: a ConstantMedium cannot be part of another medium's boundary");
+            MediumRef m; m.obj = oi; m.chain = -1;
+            if (!walk(o.children[0], chain, &m.boundary, depth + 1)) return false;
+            if (m.boundary.empty()) return fail("No bounding box in bvh constructor");  // bvh.rs:140 (empty boundary has no box)
+            m.chain = m.boundary[0].chain;
+            for (const PrimRef& p : m.boundary)
+                if (p.chain != m.chain) return fail("flatten: a medium boundary must sit under a single transform chain");
+            media.push_back(m);
+            return true;
+        }
+        }
+        return fail("flatten: unknown object type");
+    }
+
+    // ---- bounds
+    Box3 prim_box(const ObjNode& o) const {
+        Box3 bx;
+        if (o.type == OBJ_SPHERE) {  // objects.rs:241-244, with |r| so that a negative radius keeps a valid box
+            double r = std::fabs(o.p[3]);
+            bx.grow_pt(o.p[0] - r, o.p[1] - r, o.p[2] - r); bx.grow_pt(o.p[0] + r, o.p[1] + r, o.p[2] + r);
+        } else if (o.type == OBJ_MSPHERE) {  // objects.rs:328-335 at (time0, time1) = (0, 1), main.rs:531
+            double r = std::fabs(o.p[8]);
+            for (double tm = 0.0; tm <= 1.0; tm += 1.0) {
+                double s = (tm - o.p[6]) / (o.p[7] - o.p[6]);
+                double c[3] = {o.p[0] + s * (o.p[3] - o.p[0]), o.p[1] + s * (o.p[4] - o.p[1]), o.p[2] + s * (o.p[5] - o.p[2])};
+                bx.grow_pt(c[0] - r, c[1] - r, c[2] - r); bx.grow_pt(c[0] + r, c[1] + r, c[2] + r);
+            }
+        } else {  // objects.rs:413-429
+            const double off = 0.0001;
+            double x0 = o.p[0], x1 = o.p[1], y0 = o.p[2], y1 = o.p[3], k = o.p[4];
+            if (o.rect_type == Xy) { bx.grow_pt(x0, y0, k - off); bx.grow_pt(x1, y1, k + off); }
+            else if (o.rect_type == Xz) { bx.grow_pt(x0, k - off, y0); bx.grow_pt(x1, k + off, y1); }
+            else { bx.grow_pt(k - off, x0, y0); bx.grow_pt(k + off, x1, y1); }
+        }
+        return bx;
+    }
+    // Object-space box -> world box through the chain, innermost op first (transrot.rs:34-38, 60-82).
+    static Box3 chain_world_box(Box3 bx, const std::vector<Op>& ops) {
+        for (int k = (int)ops.size() - 1; k >= 0; --k) {
+            const Op& op = ops[k];
+            if (op.type == RT_OP_TRANSLATE) {
+                bx.mn[0] += op.a; bx.mx[0] += op.a; bx.mn[1] += op.b; bx.mx[1] += op.b; bx.mn[2] += op.c; bx.mx[2] += op.c;
+            } else {
+                Box3 r;
+                for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int q = 0; q < 2; ++q) {
+                    double x = i ? bx.mx[0] : bx.mn[0], y = j ? bx.mx[1] : bx.mn[1], z = q ? bx.mx[2] : bx.mn[2];
+                    r.grow_pt(op.a * x + op.b * z, y, -op.b * x + op.a * z);
+                }
+                bx = r;
+            }
+        }
+        return bx;
+    }
+    Item prim_item(const PrimRef& p) const {
+        const ObjNode& o = b.objects[p.obj];
+        Item it; it.box = prim_box(o);
+        it.cls = o.type == OBJ_SPHERE ? RT_KIND_SPHERE : (o.type == OBJ_MSPHERE ? RT_KIND_MSPHERE : RT_KIND_RECT);
+        it.ref = p.obj;
+        for (int a = 0; a < 3; ++a) it.cen[a] = 0.5 * (it.box.mn[a] + it.box.mx[a]);
+        return it;
+    }
+
+    // ---- emitters
+    int emit_prim(int oi) {  // returns the index inside the primitive's kind array
+        const ObjNode& o = b.objects[oi];
+        rt_i2 meta; meta.x = o.mat; meta.y = o.id;
+        if (o.type == OBJ_SPHERE) {
+            out.spheres.push_back(f4((float)o.p[0], (float)o.p[1], (float)o.p[2], (float)o.p[3]));
+            out.sphere_meta.push_back(meta); return (int)out.spheres.size() - 1;
+        }
+        if (o.type == OBJ_MSPHERE) {
+            out.mspheres.push_back(f4((float)o.p[0], (float)o.p[1], (float)o.p[2], (float)o.p[8]));
+            out.mspheres.push_back(f4((float)(o.p[3] - o.p[0]), (float)(o.p[4] - o.p[1]), (float)(o.p[5] - o.p[2]), (float)o.p[6]));
+            out.mspheres.push_back(f4((float)(1.0 / (o.p[7] - o.p[6])), 0, 0, 0));
+            out.msphere_meta.push_back(meta); return (int)out.msphere_meta.size() - 1;
+        }
+        out.rects.push_back(f4((float)o.p[0], (float)o.p[1], (float)o.p[2], (float)o.p[3]));
+        out.rects.push_back(f4((float)o.p[4], i2f(o.rect_type), 0, 0));
+        out.rect_meta.push_back(meta); return (int)out.rect_meta.size() - 1;
+    }
+    int emit_instance(int chain, int root) {
+        // Collapse the chain into one affine map: object point = R * world + c.
+        double cs = 1, sn = 0, c[3] = {0, 0, 0};
+        for (const Op& op : chains[chain]) {  // outermost first
+            if (op.type == RT_OP_TRANSLATE) { c[0] -= op.a; c[1] -= op.b; c[2] -= op.c; }
+            else {  // p' = Ry p : x' = cos x - sin z ; z' = sin x + cos z   (transrot.rs:96-97)
+                double x = op.a * c[0] - op.b * c[2], z = op.b * c[0] + op.a * c[2];
+                c[0] = x; c[2] = z;
+                double ncs = op.a * cs - op.b * sn, nsn = op.b * cs + op.a * sn;
+                cs = ncs; sn = nsn;
+            }
+        }
+        int first = (int)out.ops.size();
+        for (const Op& op : chains[chain])
+            out.ops.push_back(op.type == RT_OP_TRANSLATE ? f4((float)op.a, (float)op.b, (float)op.c, i2f(RT_OP_TRANSLATE))
+                                                         : f4((float)op.a, (float)op.b, 0, i2f(RT_OP_ROTATE_Y)));
+        out.instances.push_back(f4((float)cs, (float)sn, (float)c[0], (float)c[1]));
+        out.instances.push_back(f4((float)c[2], i2f(root), i2f(first), i2f((int)chains[chain].size())));
+        return (int)out.instances.size() / RT_INSTANCE_F4 - 1;
+    }
+    bool emit_medium(const MediumRef& m) {
+        const ObjNode& o = b.objects[m.obj];
+        Box3 bx;
+        int first[3] = {(int)out.spheres.size(), (int)out.msphere_meta.size(), (int)out.rect_meta.size()}, count[3] = {0, 0, 0};
+        for (int kind = 0; kind < 3; ++kind)
+            for (const PrimRef& p : m.boundary) {
+                Item it = prim_item(p);
+                if (it.cls != kind) continue;
+                emit_prim(p.obj); count[kind]++; bx.grow(it.box);
+            }
+        int inst = -1;
+        if (m.chain > 0) { inst = emit_instance(m.chain, -1); bx = chain_world_box(bx, chains[m.chain]); }
+        if (!(o.p[0] != 0.0)) return fail("constant_medium: density must be non-zero");
+        // generous fp32 bounds: the box only culls, the boundary test decides
+        double pad[3];
+        for (int a = 0; a < 3; ++a) pad[a] = 1e-5 * (std::fabs(bx.mn[a]) + std::fabs(bx.mx[a])) + 1e-4;
+        out.media.push_back(f4(f_down(bx.mn[0] - pad[0]), f_down(bx.mn[1] - pad[1]), f_down(bx.mn[2] - pad[2]), (float)(-1.0 / o.p[0])));
+        out.media.push_back(f4(f_up(bx.mx[0] + pad[0]), f_up(bx.mx[1] + pad[1]), f_up(bx.mx[2] + pad[2]), i2f(o.mat)));
+        out.media.push_back(f4(i2f(inst), i2f(first[0]), i2f(count[0]), i2f(first[1])));
+        out.media.push_back(f4(i2f(count[1]), i2f(first[2]), i2f(count[2]), i2f(o.id)));
+        return true;
+    }
+    void emit_tables() {
+        for (const MatNode& m : b.materials) {
+            out.materials.push_back(f4(i2f(m.type), i2f(m.tex), (float)m.fuzz, (float)m.ir));
+            out.materials.push_back(f4((float)m.albedo[0], (float)m.albedo[1], (float)m.albedo[2], 0));
+        }
+        for (const TexNode& t : b.textures) {
+            if (t.type == RT_TEX_CHECKER) { out.textures.push_back(f4(i2f(t.type), i2f(t.even), i2f(t.odd), 0)); out.textures.push_back(f4(0, 0, 0, 0)); }
+            else if (t.type == RT_TEX_NOISE) { out.textures.push_back(f4(i2f(t.type), i2f(t.perlin), 0, 0)); out.textures.push_back(f4((float)t.scale, 0, 0, 0)); }
+            else { out.textures.push_back(f4(i2f(t.type), 0, 0, 0)); out.textures.push_back(f4((float)t.rgb[0], (float)t.rgb[1], (float)t.rgb[2], 0)); }
+        }
+        for (const PerlinTable& p : b.perlins) {
+            for (int i = 0; i < 256; ++i) out.perlin_vec.push_back(f4((float)p.ranvec[i][0], (float)p.ranvec[i][1], (float)p.ranvec[i][2], 0));
+            for (int k = 0; k < 3; ++k) for (int i = 0; i < 256; ++i) out.perlin_perm.push_back((uint8_t)p.perm[k][i]);
+        }
+    }
+
+    // ---- BVH build
+    int new_node() { for (int i = 0; i < 4; ++i) out.nodes.push_back(f4(0, 0, 0, 0)); return (int)out.nodes.size() / 4 - 1; }
+    void set_node(int n, const Box3& l, const Box3& r, int cl, int cr) {
+        rt_f4* q = &out.nodes[(size_t)n * 4];
+        q[0] = f4(f_down(l.mn[0]), f_down(l.mn[1]), f_down(l.mn[2]), f_up(l.mx[0]));
+        q[1] = f4(f_up(l.mx[1]), f_up(l.mx[2]), f_down(r.mn[0]), f_down(r.mn[1]));
+        q[2] = f4(f_down(r.mn[2]), f_up(r.mx[0]), f_up(r.mx[1]), f_up(r.mx[2]));
+        q[3] = f4(i2f(cl), i2f(cr), 0, 0);
+    }
+    Box3 node_box(int n) const {
+        const rt_f4* q = &out.nodes[(size_t)n * 4];
+        Box3 bx; bx.grow_pt(q[0].x, q[0].y, q[0].z); bx.grow_pt(q[0].w, q[1].x, q[1].y);
+        bx.grow_pt(q[1].z, q[1].w, q[2].x); bx.grow_pt(q[2].y, q[2].z, q[2].w);
+        return bx;
+    }
+    int make_leaf(std::vector<Item>& items, size_t lo, size_t hi) {
+        if (items[lo].cls == 3) return rt_leaf_instance(items[lo].ref);
+        int first = -1;
+        for (size_t i = lo; i < hi; ++i) { int idx = emit_prim(items[i].ref); if (first < 0) first = idx; }
+        return rt_leaf_prims(items[lo].cls, first, (int)(hi - lo));
+    }
+    static bool leafable(const std::vector<Item>& items, size_t lo, size_t hi) {
+        if (hi - lo > RT_LEAF_MAX_PRIMS) return false;
+        for (size_t i = lo + 1; i < hi; ++i) if (items[i].cls != items[lo].cls) return false;
+        return items[lo].cls != 3 || hi - lo == 1;
+    }
+    // Returns a child code for items[lo,hi): a leaf code (<0) or a node index.  `depth` = inner nodes
+    // above this subtree; max_depth tracks the deepest inner-node path.
+    int build(std::vector<Item>& items, size_t lo, size_t hi, int depth, int budget, int& max_depth, Box3& box_out) {
+        Box3 bx, cb;
+        for (size_t i = lo; i < hi; ++i) { bx.grow(items[i].box); cb.grow_pt(items[i].cen[0], items[i].cen[1], items[i].cen[2]); }
+        box_out = bx;
+        size_t n = hi - lo;
+        bool can_leaf = leafable(items, lo, hi);
+        if (n == 1) return make_leaf(items, lo, hi);
+
+        size_t mid = lo;
+        bool split_found = false;
+        bool force_median = depth + ceil_log2(n) + 1 >= budget;
+        if (!force_median) {
+            const int NB = 16;
+            double best = kInf; int best_axis = -1, best_bin = -1;
+            for (int a = 0; a < 3; ++a) {
+                double ext = cb.mx[a] - cb.mn[a];
+                if (!(ext > 0)) continue;
+                Box3 bb[NB]; size_t cnt[NB] = {0};
+                for (size_t i = lo; i < hi; ++i) {
+                    int bi = std::min(NB - 1, (int)(NB * (items[i].cen[a] - cb.mn[a]) / ext));
+                    bb[bi].grow(items[i].box); cnt[bi]++;
+                }
+                double ra[NB]; size_t rc[NB]; Box3 acc; size_t c = 0;
+                for (int i = NB - 1; i > 0; --i) { acc.grow(bb[i]); c += cnt[i]; ra[i] = acc.area(); rc[i] = c; }
+                Box3 l; size_t lc = 0;
+                for (int i = 0; i < NB - 1; ++i) {
+                    l.grow(bb[i]); lc += cnt[i];
+                    if (lc == 0 || rc[i + 1] == 0) continue;
+                    double cost = l.area() * (double)lc + ra[i + 1] * (double)rc[i + 1];
+                    if (cost < best) { best = cost; best_axis = a; best_bin = i; }
+                }
+            }
+            if (best_axis >= 0) {
+                double leaf_cost = (double)n * bx.area(), split_cost = bx.area() + best;
+                if (can_leaf && leaf_cost <= split_cost) return make_leaf(items, lo, hi);
+                double ext = cb.mx[best_axis] - cb.mn[best_axis], mnv = cb.mn[best_axis];
+                auto it = std::partition(items.begin() + lo, items.begin() + hi, [&](const Item& x) {
+                    return std::min(NB - 1, (int)(NB * (x.cen[best_axis] - mnv) / ext)) <= best_bin; });
+                mid = (size_t)(it - items.begin());
+                split_found = mid > lo && mid < hi;
+            }
+        }
+        if (!split_found) {
+            if (can_leaf) return make_leaf(items, lo, hi);
+            int axis = 0; double e = -1;
+            for (int a = 0; a < 3; ++a) if (cb.mx[a] - cb.mn[a] > e) { e = cb.mx[a] - cb.mn[a]; axis = a; }
+            mid = lo + n / 2;
+            std::nth_element(items.begin() + lo, items.begin() + mid, items.begin() + hi,
+                             [axis](const Item& x, const Item& y) { return x.cen[axis] < y.cen[axis]; });
+        }
+        int node = new_node();
+        max_depth = std::max(max_depth, depth + 1);
+        Box3 lb, rb;
+        int cl = build(items, lo, mid, depth + 1, budget, max_depth, lb);
+        int cr = build(items, mid, hi, depth + 1, budget, max_depth, rb);
+        set_node(node, lb, rb, cl, cr);
+        return node;
+    }
+    // Builds a BVH whose root is always an inner node (a lone leaf is referenced by both children).
+    int build_root(std::vector<Item>& items, int budget, int& depth) {
+        Box3 bx; depth = 0;
+        int code = build(items, 0, items.size(), 0, budget, depth, bx);
+        if (code >= 0) return code;
+        int node = new_node();
+        set_node(node, bx, bx, code, code);
+        depth = 1;
+        return node;
+    }
+};
+
+}  // namespace
+
+RtSceneView FlatScene::view() const {
+    RtSceneView v; std::memset(&v, 0, sizeof(v));
+    v.nodes = nodes.data(); v.spheres = spheres.data(); v.sphere_meta = sphere_meta.data();
+    v.mspheres = mspheres.data(); v.msphere_meta = msphere_meta.data(); v.rects = rects.data(); v.rect_meta = rect_meta.data();
+    v.instances = instances.data(); v.ops = ops.data(); v.media = media.data(); v.materials = materials.data();
+    v.textures = textures.data(); v.perlin_vec = perlin_vec.data(); v.perlin_perm = perlin_perm.data();
+    v.root = root;
+    v.n_nodes = (int)nodes.size() / 4; v.n_spheres = (int)spheres.size(); v.n_mspheres = (int)msphere_meta.size();
+    v.n_rects = (int)rect_meta.size(); v.n_instances = (int)instances.size() / RT_INSTANCE_F4; v.n_ops = (int)ops.size();
+    v.n_media = (int)media.size() / RT_MEDIUM_F4; v.n_materials = (int)materials.size() / RT_MATERIAL_F4;
+    v.n_textures = (int)textures.size() / RT_TEXTURE_F4; v.n_perlin = (int)perlin_vec.size() / RT_PERLIN_VEC_F4;
+    v.max_stack = max_stack;
+    return v;
+}
+
+bool flatten(const Builder& b, HittableObj world, FlatScene& out, std::string& err) {
+    err.clear();
+    Flattener f(b, out, err);
+    return f.run(world);
+}
+
+}  // namespace rt

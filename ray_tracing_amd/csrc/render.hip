@@ -1,0 +1,481 @@
+// render.hip -- gfx950 kernels and the host code that drives them (the "rt_*" half of include/rt_hip.h).
+//
+// Wavefront organisation of one pass over P = W*H*spp_chunk paths (replaces src/main.rs:567-599):
+//   k_raygen      : Philox camera rays (pixel jitter, lens, shutter time) -> ray queue 0
+//   k_bounce x D  : for every queued ray: closest hit (two-level BVH + media), scatter, and append of
+//                   the scattered ray to the other queue through a wave-aggregated atomic (one
+//                   atomic per 64-lane wave, ranks from ballot + mbcnt); terminated paths add their
+//                   radiance to their private slot of the contribution buffer
+//   k_accumulate  : per pixel, sums the pass's contributions in sample order into the caller's
+//                   accumulation buffer (deterministic; no float atomics anywhere)
+// Queue sizes live in device memory (counts[b] = rays entering bounce b), so a pass runs without a
+// host round trip; the counts double as the ray-segment statistics.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "capi_internal.h"
+#include "rt_device.h"
+
+#define RT_BLOCK 256
+#define RT_MAX_BOUNCE_COUNTS 1024
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return rt_set_error(e_ == hipErrorOutOfMemory ? RT_ERR_OOM : RT_ERR_HIP,                    \
+                                std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+    } while (0)
+
+// ------------------------------------------------------------------ device side
+struct LdsStack {  // one column of the block's LDS stack: entry i of thread t lives at [i][t]
+    int* base;
+    __host__ __device__ void set(int i, int v) { base[i * RT_BLOCK] = v; }
+    __host__ __device__ int get(int i) const { return base[i * RT_BLOCK]; }
+};
+
+__global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev fr, uint32_t n_paths, uint32_t* counts,
+                                                     rt_f4* qa, rt_f4* qb, rt_f4* qc) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[1] = n_paths;
+    for (uint32_t pid = blockIdx.x * RT_BLOCK + threadIdx.x; pid < n_paths; pid += gridDim.x * RT_BLOCK) {
+        uint32_t pixel = pid % (uint32_t)fr.n_pixels, s = pid / (uint32_t)fr.n_pixels;
+        v3 o, d; float time;
+        rt_camera_ray(cam, fr, pixel, (uint32_t)fr.sample_base + s, o, d, time);
+        rt_f4 a, b, c;
+        a.x = o.x; a.y = o.y; a.z = o.z; a.w = time;
+        b.x = d.x; b.y = d.y; b.z = d.z; b.w = i2f((int)RT_HIT_NONE);
+        c.x = 1.0f; c.y = 1.0f; c.z = 1.0f; c.w = i2f((int)pid);
+        *reinterpret_cast<float4*>(qa + pid) = make_float4(a.x, a.y, a.z, a.w);
+        *reinterpret_cast<float4*>(qb + pid) = make_float4(b.x, b.y, b.z, b.w);
+        *reinterpret_cast<float4*>(qc + pid) = make_float4(c.x, c.y, c.z, c.w);
+    }
+}
+
+// One bounce for every ray of the input queue (lib.rs:63-71, iteratively).
+__global__ __launch_bounds__(RT_BLOCK) void k_bounce(RtSceneView sc, RtFrameDev fr, int bounce, const uint32_t* n_in_ptr,
+                                                     uint32_t* n_out_ptr, const rt_f4* ia, const rt_f4* ib, const rt_f4* ic,
+                                                     rt_f4* oa, rt_f4* ob, rt_f4* oc, rt_f4* contrib) {
+    __shared__ int s_stack[RT_STACK_DEPTH * RT_BLOCK];
+    LdsStack stk; stk.base = s_stack + threadIdx.x;
+    const uint32_t n = *n_in_ptr;
+    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
+        uint32_t i = base + threadIdx.x;
+        bool alive = false;
+        rt_f4 na, nb, nc;
+        na.x = na.y = na.z = na.w = nb.x = nb.y = nb.z = nb.w = nc.x = nc.y = nc.z = nc.w = 0.0f;
+        if (i < n) {
+            rt_f4 a = ld4(ia + i), b = ld4(ib + i), c = ld4(ic + i);
+            v3 o = mk3(a.x, a.y, a.z), d = mk3(b.x, b.y, b.z), beta = mk3(c.x, c.y, c.z);
+            float time = a.w;
+            uint32_t src = (uint32_t)f2i(b.w), pid = (uint32_t)f2i(c.w);
+            uint32_t pixel = pid % (uint32_t)fr.n_pixels, sample = (uint32_t)fr.sample_base + pid / (uint32_t)fr.n_pixels;
+
+            RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
+            rt_closest_hit(sc, o, d, time, RT_TMIN, src, stk, hit);
+            if (sc.n_media > 0) rt_media_hits(sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, hit);
+
+            v3 add = mk3(0, 0, 0);
+            if (hit.code == RT_HIT_NONE) {
+                add = beta * mk3(fr.background[0], fr.background[1], fr.background[2]);  // lib.rs:76
+            } else {
+                RtSurface sf;
+                rt_surface(sc, o, d, time, hit, false, sf);
+                uint32_t rnd[4];
+                rt_philox(pixel, sample, (uint32_t)bounce, 0u, fr.key0, fr.key1, rnd);
+                v3 atten, dir, emitted;
+                bool scattered = rt_scatter(sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), rt_u24(rnd[2]), atten, dir, emitted);
+                add = beta * emitted;                                                      // lib.rs:64,66
+                if (scattered && bounce < fr.max_depth) {                                 // lib.rs:58-60
+                    beta = beta * atten;
+                    alive = true;
+                    na.x = sf.p.x; na.y = sf.p.y; na.z = sf.p.z; na.w = time;
+                    nb.x = dir.x; nb.y = dir.y; nb.z = dir.z;
+                    nb.w = i2f(RT_HIT_KIND(hit.code) == RT_KIND_MEDIUM ? (int)RT_HIT_NONE : (int)hit.code);
+                    nc.x = beta.x; nc.y = beta.y; nc.z = beta.z; nc.w = c.w;
+                }
+            }
+            if (add.x != 0.0f || add.y != 0.0f || add.z != 0.0f) {
+                float4* cp = reinterpret_cast<float4*>(contrib + pid);
+                float4 cv = *cp;
+                cv.x += add.x; cv.y += add.y; cv.z += add.z;
+                *cp = cv;
+            }
+        }
+        // wave-aggregated append: one atomic per wave, slot = base + rank among the live lanes
+        unsigned long long mask = __ballot(alive);
+        if (mask) {
+            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            uint32_t slot0 = 0;
+            if (alive && rank == 0) slot0 = atomicAdd(n_out_ptr, (uint32_t)__popcll(mask));
+            slot0 = __shfl(slot0, __ffsll((long long)mask) - 1);
+            if (alive) {
+                uint32_t slot = slot0 + rank;
+                *reinterpret_cast<float4*>(oa + slot) = make_float4(na.x, na.y, na.z, na.w);
+                *reinterpret_cast<float4*>(ob + slot) = make_float4(nb.x, nb.y, nb.z, nb.w);
+                *reinterpret_cast<float4*>(oc + slot) = make_float4(nc.x, nc.y, nc.z, nc.w);
+            }
+        }
+    }
+}
+
+// accum[pixel] += sum over the pass's samples, in sample order (main.rs:585-589).
+__global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const rt_f4* contrib, int n_pixels, int spp_chunk, float* accum, float* accum_sq) {
+    int pixel = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (pixel >= n_pixels) return;
+    float sx = 0, sy = 0, sz = 0, qx = 0, qy = 0, qz = 0;
+    for (int s = 0; s < spp_chunk; ++s) {
+        rt_f4 c = ld4(contrib + (size_t)s * n_pixels + pixel);
+        sx += c.x; sy += c.y; sz += c.z;
+        qx = fmaf(c.x, c.x, qx); qy = fmaf(c.y, c.y, qy); qz = fmaf(c.z, c.z, qz);
+    }
+    accum[3 * (size_t)pixel] += sx; accum[3 * (size_t)pixel + 1] += sy; accum[3 * (size_t)pixel + 2] += sz;
+    if (accum_sq) { accum_sq[3 * (size_t)pixel] += qx; accum_sq[3 * (size_t)pixel + 1] += qy; accum_sq[3 * (size_t)pixel + 2] += qz; }
+}
+
+// Parity hook: closest hit of one sample per pixel.
+__global__ __launch_bounds__(RT_BLOCK) void k_primary(RtSceneView sc, RtCameraDev cam, RtFrameDev fr, uint32_t sample, int32_t* ids,
+                                                      float* ts, float* normals, int32_t* fronts, float* uvs) {
+    __shared__ int s_stack[RT_STACK_DEPTH * RT_BLOCK];
+    LdsStack stk; stk.base = s_stack + threadIdx.x;
+    uint32_t pixel = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (pixel >= (uint32_t)fr.n_pixels) return;
+    v3 o, d; float time;
+    rt_camera_ray(cam, fr, pixel, sample, o, d, time);
+    RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
+    rt_closest_hit(sc, o, d, time, RT_TMIN, RT_HIT_NONE, stk, hit);
+    if (sc.n_media > 0) rt_media_hits(sc, o, d, time, RT_TMIN, pixel, sample, 1u, fr.key0, fr.key1, hit);
+    RtSurface sf; sf.id = -1; sf.n = mk3(0, 0, 0); sf.front = false; sf.u = sf.v = 0.0f;
+    if (hit.code != RT_HIT_NONE) rt_surface(sc, o, d, time, hit, true, sf);
+    ids[pixel] = sf.id; ts[pixel] = hit.t;
+    if (normals) { normals[3 * pixel] = sf.n.x; normals[3 * pixel + 1] = sf.n.y; normals[3 * pixel + 2] = sf.n.z; }
+    if (fronts) fronts[pixel] = sf.front ? 1 : 0;
+    if (uvs) { uvs[2 * pixel] = sf.u; uvs[2 * pixel + 1] = sf.v; }
+}
+
+// Parity hook: one scatter event per explicit ray.
+__global__ __launch_bounds__(RT_BLOCK) void k_scatter_rays(RtSceneView sc, const float* rays, int n, uint32_t pixel0, uint32_t sample, int bounce,
+                                                           uint32_t key0, uint32_t key1, float* out) {
+    __shared__ int s_stack[RT_STACK_DEPTH * RT_BLOCK];
+    LdsStack stk; stk.base = s_stack + threadIdx.x;
+    int i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + 7 * (size_t)i;
+    v3 o = mk3(r[0], r[1], r[2]), d = mk3(r[3], r[4], r[5]); float time = r[6];
+    uint32_t pixel = pixel0 + (uint32_t)i;
+    RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
+    rt_closest_hit(sc, o, d, time, RT_TMIN, RT_HIT_NONE, stk, hit);
+    if (sc.n_media > 0) rt_media_hits(sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, key0, key1, hit);
+    float* w = out + 14 * (size_t)i;
+    for (int k = 0; k < 14; ++k) w[k] = 0.0f;
+    if (hit.code == RT_HIT_NONE) { w[0] = -1.0f; return; }
+    RtSurface sf; rt_surface(sc, o, d, time, hit, false, sf);
+    uint32_t rnd[4]; rt_philox(pixel, sample, (uint32_t)bounce, 0u, key0, key1, rnd);
+    v3 atten, dir, emitted;
+    bool sc_ok = rt_scatter(sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), rt_u24(rnd[2]), atten, dir, emitted);
+    w[0] = sc_ok ? 1.0f : 0.0f;
+    w[1] = emitted.x; w[2] = emitted.y; w[3] = emitted.z; w[4] = atten.x; w[5] = atten.y; w[6] = atten.z;
+    w[7] = sf.p.x; w[8] = sf.p.y; w[9] = sf.p.z; w[10] = dir.x; w[11] = dir.y; w[12] = dir.z; w[13] = time;
+}
+
+// ------------------------------------------------------------------ host side
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+};
+struct RtScene {
+    int device = 0, n_cu = 0;
+    rt::FlatScene flat;            // host copy (info only after upload)
+    RtSceneView view;              // device pointers
+    std::vector<void*> allocs;     // scene arrays
+    uint64_t device_bytes = 0;
+    // render workspace (grow-only)
+    size_t ws_paths = 0;
+    rt_f4 *qa[2] = {nullptr, nullptr}, *qb[2] = {nullptr, nullptr}, *qc[2] = {nullptr, nullptr}, *contrib = nullptr;
+    uint32_t* counts = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+template <class T>
+static int upload(RtScene* s, const std::vector<T>& v, const T** out) {
+    *out = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);  // never a null array: kernels may form the base address
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    s->allocs.push_back(d);
+    s->device_bytes += bytes;
+    if (!v.empty()) HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    else HIP_TRY(hipMemset(d, 0, bytes));
+    *out = (const T*)d;
+    return RT_OK;
+}
+
+static void free_workspace(RtScene* s) {
+    for (int i = 0; i < 2; ++i) { if (s->qa[i]) (void)hipFree(s->qa[i]); if (s->qb[i]) (void)hipFree(s->qb[i]); if (s->qc[i]) (void)hipFree(s->qc[i]); s->qa[i] = s->qb[i] = s->qc[i] = nullptr; }
+    if (s->contrib) (void)hipFree(s->contrib);
+    s->contrib = nullptr; s->ws_paths = 0;
+}
+static int ensure_workspace(RtScene* s, size_t n_paths) {
+    if (!s->counts) { HIP_TRY(hipMalloc((void**)&s->counts, RT_MAX_BOUNCE_COUNTS * sizeof(uint32_t))); }
+    if (!s->ev0) { HIP_TRY(hipEventCreate(&s->ev0)); HIP_TRY(hipEventCreate(&s->ev1)); }
+    if (s->ws_paths >= n_paths) return RT_OK;
+    free_workspace(s);
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipMalloc((void**)&s->qa[i], n_paths * sizeof(rt_f4)));
+        HIP_TRY(hipMalloc((void**)&s->qb[i], n_paths * sizeof(rt_f4)));
+        HIP_TRY(hipMalloc((void**)&s->qc[i], n_paths * sizeof(rt_f4)));
+    }
+    HIP_TRY(hipMalloc((void**)&s->contrib, n_paths * sizeof(rt_f4)));
+    s->ws_paths = n_paths;
+    return RT_OK;
+}
+
+static int check_common(const RtScene* s, const RtCamera* cam, const RtRenderParams* p) {
+    if (!s || !cam || !p) return rt_set_error(RT_ERR_INVALID, "null argument");
+    if (p->width < 2 || p->height < 2) return rt_set_error(RT_ERR_INVALID, "width and height must be >= 2 (main.rs:572-573 divides by W-1, H-1)");
+    if ((uint64_t)p->width * (uint64_t)p->height > 0x7FFFFFFFull / 4) return rt_set_error(RT_ERR_INVALID, "image too large");
+    if (p->max_depth < 0 || p->max_depth > RT_MAX_BOUNCE_COUNTS - 2) return rt_set_error(RT_ERR_INVALID, "max_depth out of range");
+    if (s->flat.max_stack > RT_STACK_DEPTH) return rt_set_error(RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+    return RT_OK;
+}
+
+static void make_frame(const RtRenderParams* p, RtFrameDev& fr) {
+    std::memset(&fr, 0, sizeof(fr));
+    fr.width = p->width; fr.height = p->height; fr.n_pixels = p->width * p->height;
+    fr.max_depth = p->max_depth;
+    fr.key0 = (uint32_t)p->seed; fr.key1 = (uint32_t)(p->seed >> 32);
+    fr.inv_wm1 = (float)(1.0 / (double)(p->width - 1)); fr.inv_hm1 = (float)(1.0 / (double)(p->height - 1));
+    for (int c = 0; c < 3; ++c) fr.background[c] = p->background[c];
+}
+static void make_cam(const RtCamera* cam, RtCameraDev& cd) {
+    rt::CameraDesc d;
+    d.look_from = rt::vec3(cam->look_from[0], cam->look_from[1], cam->look_from[2]);
+    d.look_at = rt::vec3(cam->look_at[0], cam->look_at[1], cam->look_at[2]);
+    d.v_up = rt::vec3(cam->v_up[0], cam->v_up[1], cam->v_up[2]);
+    d.vertical_fov_deg = cam->vertical_fov_deg; d.aspect_ratio = cam->aspect_ratio; d.aperture = cam->aperture;
+    d.focus_dist = cam->focus_dist; d.shutter_open = cam->shutter_open; d.shutter_close = cam->shutter_close;
+    rt::make_camera(d, cd);
+}
+
+extern "C" {
+
+int rt_device_count(int* count) {
+    if (!count) return rt_set_error(RT_ERR_INVALID, "null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return rt_set_error(RT_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *count = n;
+    return RT_OK;
+}
+
+int rt_scene_create(const RtBuilder* b, RtObj world, int device, RtScene** out) {
+    if (!b || !out) return rt_set_error(RT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    RtFlat* flat = nullptr;
+    int rc = rt_flat_create(b, world, &flat);
+    if (rc != RT_OK) return rc;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { rt_flat_destroy(flat); return rt_set_error(RT_ERR_NO_DEVICE, "no HIP device available"); }
+    if (device < 0 || device >= n_dev) { rt_flat_destroy(flat); return rt_set_error(RT_ERR_INVALID, "device index out of range"); }
+    RtScene* s = new RtScene;
+    s->device = device;
+    s->flat = flat->flat;
+    rt_flat_destroy(flat);
+    rc = [&]() -> int {
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipDeviceGetAttribute(&s->n_cu, hipDeviceAttributeMultiprocessorCount, device));
+        const rt::FlatScene& f = s->flat;
+        RtSceneView v = f.view();
+        int r;
+        if ((r = upload(s, f.nodes, &v.nodes))) return r;
+        if ((r = upload(s, f.spheres, &v.spheres))) return r;
+        if ((r = upload(s, f.sphere_meta, &v.sphere_meta))) return r;
+        if ((r = upload(s, f.mspheres, &v.mspheres))) return r;
+        if ((r = upload(s, f.msphere_meta, &v.msphere_meta))) return r;
+        if ((r = upload(s, f.rects, &v.rects))) return r;
+        if ((r = upload(s, f.rect_meta, &v.rect_meta))) return r;
+        if ((r = upload(s, f.instances, &v.instances))) return r;
+        if ((r = upload(s, f.ops, &v.ops))) return r;
+        if ((r = upload(s, f.media, &v.media))) return r;
+        if ((r = upload(s, f.materials, &v.materials))) return r;
+        if ((r = upload(s, f.textures, &v.textures))) return r;
+        if ((r = upload(s, f.perlin_vec, &v.perlin_vec))) return r;
+        if ((r = upload(s, f.perlin_perm, &v.perlin_perm))) return r;
+        s->view = v;
+        return RT_OK;
+    }();
+    if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
+    *out = s;
+    return RT_OK;
+}
+
+void rt_scene_destroy(RtScene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    for (void* p : s->allocs) (void)hipFree(p);
+    free_workspace(s);
+    if (s->counts) (void)hipFree(s->counts);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    delete s;
+}
+
+static void fill_info(const rt::FlatScene& f, RtSceneInfo* o) {
+    RtSceneView v = f.view();
+    o->n_nodes = v.n_nodes; o->n_spheres = v.n_spheres; o->n_moving_spheres = v.n_mspheres; o->n_rects = v.n_rects;
+    o->n_instances = v.n_instances; o->n_media = v.n_media; o->n_materials = v.n_materials; o->n_textures = v.n_textures; o->n_perlin = v.n_perlin;
+    o->tlas_depth = f.tlas_depth; o->blas_depth = f.blas_depth; o->max_stack = f.max_stack; o->n_objects = f.n_ids; o->device = -1;
+    for (int i = 0; i < 6; ++i) o->world_box[i] = f.world_box[i];
+    o->device_bytes = 0;
+}
+int rt_scene_info(const RtScene* s, RtSceneInfo* out) {
+    if (!s || !out) return rt_set_error(RT_ERR_INVALID, "null argument");
+    fill_info(s->flat, out); out->device = s->device; out->device_bytes = s->device_bytes;
+    return RT_OK;
+}
+int rt_flat_info(const RtFlat* f, RtSceneInfo* out) {
+    if (!f || !out) return rt_set_error(RT_ERR_INVALID, "null argument");
+    fill_info(f->flat, out);
+    return RT_OK;
+}
+
+int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* d_accum, float* d_accum_sq, void* hip_stream, RtStats* stats) {
+    int rc = check_common(s, cam, p);
+    if (rc) return rc;
+    if (!d_accum) return rt_set_error(RT_ERR_INVALID, "null accumulation buffer");
+    if (p->spp < 0) return rt_set_error(RT_ERR_INVALID, "spp must be >= 0");
+    if ((p->flags & RT_FLAG_SUMSQ) && !d_accum_sq) return rt_set_error(RT_ERR_INVALID, "RT_FLAG_SUMSQ needs accum_sq");
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(s->device));
+    auto t_begin = std::chrono::steady_clock::now();
+
+    RtCameraDev cd; make_cam(cam, cd);
+    RtFrameDev fr; make_frame(p, fr);
+    const size_t n_pixels = (size_t)fr.n_pixels;
+    size_t target = p->paths_per_pass > 0 ? (size_t)p->paths_per_pass : ((size_t)1 << 23);
+    int chunk_max = (int)std::max<size_t>(1, target / n_pixels);
+    if ((size_t)chunk_max * n_pixels > 0xFFFFFFF0ull) chunk_max = (int)(0xFFFFFFF0ull / n_pixels);
+    chunk_max = std::min(chunk_max, std::max(1, p->spp));
+    if ((rc = ensure_workspace(s, (size_t)chunk_max * n_pixels))) return rc;
+
+    RtStats local; std::memset(&local, 0, sizeof(local));
+    local.paths = (uint64_t)n_pixels * (uint64_t)p->spp;
+    std::vector<uint32_t> h_counts(RT_MAX_BOUNCE_COUNTS);
+    const int grid_cap = std::max(1, s->n_cu) * 32;
+    float* sq = (p->flags & RT_FLAG_SUMSQ) ? d_accum_sq : nullptr;
+
+    for (int done = 0; done < p->spp;) {
+        int chunk = std::min(chunk_max, p->spp - done);
+        uint32_t n_paths = (uint32_t)((size_t)chunk * n_pixels);
+        fr.spp_chunk = chunk; fr.sample_base = p->sample_offset + done;
+        HIP_TRY(hipMemsetAsync(s->counts, 0, (size_t)(p->max_depth + 2) * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(s->contrib, 0, (size_t)n_paths * sizeof(rt_f4), st));
+        int grid = (int)std::min<size_t>(((size_t)n_paths + RT_BLOCK - 1) / RT_BLOCK, (size_t)grid_cap);
+        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, cd, fr, n_paths, s->counts, s->qa[0], s->qb[0], s->qc[0]);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(s->ev0, st));
+        for (int b = 1; b <= p->max_depth; ++b) {
+            int in = (b - 1) & 1, outq = b & 1;
+            hipLaunchKernelGGL(k_bounce, dim3(grid), dim3(RT_BLOCK), 0, st, s->view, fr, b, s->counts + b, s->counts + b + 1,
+                               s->qa[in], s->qb[in], s->qc[in], s->qa[outq], s->qb[outq], s->qc[outq], s->contrib);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(s->ev1, st));
+        int agrid = (int)((n_pixels + RT_BLOCK - 1) / RT_BLOCK);
+        hipLaunchKernelGGL(k_accumulate, dim3(agrid), dim3(RT_BLOCK), 0, st, s->contrib, (int)n_pixels, chunk, d_accum, sq);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_counts.data(), s->counts, (size_t)(p->max_depth + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+        local.kernel_ms_extend += ms; local.extend_launches += (uint64_t)p->max_depth; local.passes++;
+        for (int b = 1; b <= p->max_depth; ++b) {
+            local.rays += h_counts[b];
+            if (b <= 64) local.rays_per_bounce[b - 1] += h_counts[b];
+        }
+        done += chunk;
+    }
+    local.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    if (stats) *stats = local;
+    return RT_OK;
+}
+
+int rt_render(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* accum, float* accum_sq, RtStats* stats) {
+    int rc = check_common(s, cam, p);
+    if (rc) return rc;
+    if (!accum) return rt_set_error(RT_ERR_INVALID, "null accumulation buffer");
+    if ((p->flags & RT_FLAG_SUMSQ) && !accum_sq) return rt_set_error(RT_ERR_INVALID, "RT_FLAG_SUMSQ needs accum_sq");
+    HIP_TRY(hipSetDevice(s->device));
+    size_t n = (size_t)p->width * p->height * 3;
+    float *d_acc = nullptr, *d_sq = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_acc, n * sizeof(float)));
+    hipError_t e = hipMemset(d_acc, 0, n * sizeof(float));
+    if (e == hipSuccess && (p->flags & RT_FLAG_SUMSQ)) { e = hipMalloc((void**)&d_sq, n * sizeof(float)); if (e == hipSuccess) e = hipMemset(d_sq, 0, n * sizeof(float)); }
+    if (e != hipSuccess) { (void)hipFree(d_acc); if (d_sq) (void)hipFree(d_sq); return rt_set_error(RT_ERR_HIP, std::string("rt_render alloc: ") + hipGetErrorString(e)); }
+    rc = rt_render_device(s, cam, p, d_acc, d_sq, nullptr, stats);
+    if (rc == RT_OK) {
+        std::vector<float> tmp(n);
+        e = hipMemcpy(tmp.data(), d_acc, n * sizeof(float), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) for (size_t i = 0; i < n; ++i) accum[i] += tmp[i];
+        if (e == hipSuccess && d_sq) {
+            e = hipMemcpy(tmp.data(), d_sq, n * sizeof(float), hipMemcpyDeviceToHost);
+            if (e == hipSuccess) for (size_t i = 0; i < n; ++i) accum_sq[i] += tmp[i];
+        }
+        if (e != hipSuccess) rc = rt_set_error(RT_ERR_HIP, std::string("rt_render copy: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(d_acc); if (d_sq) (void)hipFree(d_sq);
+    return rc;
+}
+
+int rt_trace_primary(RtScene* s, const RtCamera* cam, const RtRenderParams* p, int32_t sample, int32_t* ids, float* ts, float* normals,
+                     int32_t* fronts, float* uvs) {
+    int rc = check_common(s, cam, p);
+    if (rc) return rc;
+    if (!ids || !ts) return rt_set_error(RT_ERR_INVALID, "null output buffer");
+    HIP_TRY(hipSetDevice(s->device));
+    RtCameraDev cd; make_cam(cam, cd);
+    RtFrameDev fr; make_frame(p, fr);
+    size_t n = (size_t)fr.n_pixels;
+    int32_t *d_ids = nullptr, *d_fr = nullptr; float *d_t = nullptr, *d_n = nullptr, *d_uv = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_ids); (void)hipFree(d_t); if (d_n) (void)hipFree(d_n); if (d_fr) (void)hipFree(d_fr); if (d_uv) (void)hipFree(d_uv); };
+    rc = [&]() -> int {
+        HIP_TRY(hipMalloc((void**)&d_ids, n * 4)); HIP_TRY(hipMalloc((void**)&d_t, n * 4));
+        if (normals) HIP_TRY(hipMalloc((void**)&d_n, n * 12));
+        if (fronts) HIP_TRY(hipMalloc((void**)&d_fr, n * 4));
+        if (uvs) HIP_TRY(hipMalloc((void**)&d_uv, n * 8));
+        int grid = (int)((n + RT_BLOCK - 1) / RT_BLOCK);
+        hipLaunchKernelGGL(k_primary, dim3(grid), dim3(RT_BLOCK), 0, 0, s->view, cd, fr, (uint32_t)sample, d_ids, d_t, d_n, d_fr, d_uv);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(ids, d_ids, n * 4, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(ts, d_t, n * 4, hipMemcpyDeviceToHost));
+        if (normals) HIP_TRY(hipMemcpy(normals, d_n, n * 12, hipMemcpyDeviceToHost));
+        if (fronts) HIP_TRY(hipMemcpy(fronts, d_fr, n * 4, hipMemcpyDeviceToHost));
+        if (uvs) HIP_TRY(hipMemcpy(uvs, d_uv, n * 8, hipMemcpyDeviceToHost));
+        return RT_OK;
+    }();
+    cleanup();
+    return rc;
+}
+
+int rt_scatter_rays(RtScene* s, const float* rays, int32_t n, uint32_t pixel0, uint32_t sample, int32_t bounce, uint64_t seed, float* out) {
+    if (!s || !rays || !out || n < 0) return rt_set_error(RT_ERR_INVALID, "bad argument");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    float *d_r = nullptr, *d_o = nullptr;
+    int rc = [&]() -> int {
+        HIP_TRY(hipMalloc((void**)&d_r, (size_t)n * 28)); HIP_TRY(hipMalloc((void**)&d_o, (size_t)n * 56));
+        HIP_TRY(hipMemcpy(d_r, rays, (size_t)n * 28, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_scatter_rays, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, 0, s->view, d_r, n, pixel0, sample, bounce,
+                           (uint32_t)seed, (uint32_t)(seed >> 32), d_o);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(out, d_o, (size_t)n * 56, hipMemcpyDeviceToHost));
+        return RT_OK;
+    }();
+    if (d_r) (void)hipFree(d_r);
+    if (d_o) (void)hipFree(d_o);
+    return rc;
+}
+
+}  // extern "C"

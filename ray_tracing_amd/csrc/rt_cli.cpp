@@ -1,0 +1,61 @@
+// rt_cli.cpp -- command-line driver with the flags of the reference binary (main.rs:496-504):
+//   rt_cli -c <config.yml> [-o <image.ppm>]      plus  --spp N  --seed N  --scene-seed N  --device N  --background r,g,b
+// It does what main() does (main.rs:506-601) with the render loop replaced by rt_render: read the
+// config, build the scene, render samples_per_pixel samples, tonemap (utils.rs:49-63), save.
+// Output is a binary PPM of the same 8-bit values the reference hands to its image encoder
+// (its default is a lossy JPEG, main.rs:502).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/rt_hip.h"
+
+static int die(const char* what) { std::fprintf(stderr, "rt_cli: %s: %s\n", what, rt_last_error()); return 1; }
+
+int main(int argc, char** argv) {
+    std::string config, output = "./image.ppm";
+    long long spp_override = -1; unsigned long long seed = 0x5EED0002ull, scene_seed = 0x5EED0001ull; int device = 0;
+    float bg[3] = {0, 0, 0};
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&](const char* flag) -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "rt_cli: %s needs a value\n", flag); std::exit(2); } return argv[++i]; };
+        if (a == "-c" || a == "--config") config = next("--config");
+        else if (a == "-o" || a == "--output") output = next("--output");
+        else if (a == "--spp") spp_override = std::atoll(next("--spp"));
+        else if (a == "--seed") seed = std::strtoull(next("--seed"), nullptr, 0);
+        else if (a == "--scene-seed") scene_seed = std::strtoull(next("--scene-seed"), nullptr, 0);
+        else if (a == "--device") device = std::atoi(next("--device"));
+        else if (a == "--background") { if (std::sscanf(next("--background"), "%f,%f,%f", &bg[0], &bg[1], &bg[2]) != 3) { std::fprintf(stderr, "rt_cli: --background r,g,b\n"); return 2; } }
+        else { std::fprintf(stderr, "usage: rt_cli -c <config.yml> [-o <image.ppm>] [--spp N] [--seed N] [--scene-seed N] [--device N] [--background r,g,b]\n"); return 2; }
+    }
+    if (config.empty()) { std::fprintf(stderr, "rt_cli: the following required arguments were not provided: --config <CONFIG>\n"); return 2; }
+
+    RtConfig cfg;
+    if (rt_config_load(config.c_str(), &cfg)) return die("config");
+    RtBuilder* b = nullptr; RtObj world = -1;
+    if (rtb_create(&b) || rt_config_build_scene(config.c_str(), scene_seed, b, &world)) return die("scene");
+    RtScene* scene = nullptr;
+    if (rt_scene_create(b, world, device, &scene)) return die("rt_scene_create");
+    rtb_destroy(b);
+
+    RtCamera cam;
+    std::memcpy(cam.look_from, cfg.look_from, sizeof(cam.look_from)); std::memcpy(cam.look_at, cfg.look_at, sizeof(cam.look_at));
+    std::memcpy(cam.v_up, cfg.v_up, sizeof(cam.v_up));
+    cam.vertical_fov_deg = cfg.vertical_fov_deg; cam.aspect_ratio = cfg.aspect_ratio; cam.aperture = cfg.aperture; cam.focus_dist = cfg.focus_distance;
+    cam.shutter_open = 0.0; cam.shutter_close = 1.0;  // main.rs:544-546
+    RtRenderParams p; std::memset(&p, 0, sizeof(p));
+    p.width = cfg.image_width; p.height = cfg.image_height; p.spp = spp_override > 0 ? (int)spp_override : cfg.samples_per_pixel;
+    p.max_depth = cfg.max_depth; p.seed = seed; std::memcpy(p.background, bg, sizeof(bg));
+
+    std::vector<float> accum((size_t)p.width * p.height * 3, 0.0f);
+    RtStats st;
+    if (rt_render(scene, &cam, &p, accum.data(), nullptr, &st)) return die("rt_render");
+    std::vector<uint8_t> rgb(accum.size());
+    if (rt_tonemap_u8(accum.data(), p.width * p.height, p.spp, rgb.data())) return die("tonemap");
+    if (rt_write_ppm(output.c_str(), rgb.data(), p.width, p.height)) return die("write");
+    std::fprintf(stderr, "%s: %dx%d, %d spp, depth %d: %.3f s, %llu ray segments, %.1f Mrays/s -> %s\n", cfg.scene_type, p.width, p.height, p.spp,
+                 p.max_depth, st.seconds, (unsigned long long)st.rays, st.rays / st.seconds / 1e6, output.c_str());
+    rt_scene_destroy(scene);
+    return 0;
+}

@@ -1,0 +1,522 @@
+// rt_device.h -- the fp32 path-tracing arithmetic of the gfx950 kernels, written as inline
+// functions so that kernels.hip can arrange them into wavefront stages.  The functions restate,
+// in fp32 and without recursion or virtual dispatch, the per-ray work of the reference:
+//   camera ray          cameras.rs:82-98        closest hit   bvh.rs:159-187, objects.rs:67-78
+//   sphere              objects.rs:205-239      moving sphere objects.rs:292-326
+//   rectangle           objects.rs:384-411      instances     transrot.rs:20-32, 92-116
+//   constant medium     mediums.rs:39-87        materials     materials.rs:77-90,129-145,181-209,243-249,276-283
+//   textures            textures.rs:28-32,60-69,87-96,131-170,214-237
+// The file also compiles as plain C++ (RT_HD then means "static inline"): tests/emul builds it on
+// the CPU to debug the fp32 logic without a GPU.  That build is test-only and never shipped.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include "rt_types.h"
+
+#if defined(__HIPCC__)
+#define RT_HD __host__ __device__ __forceinline__
+#else
+#define RT_HD static inline
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RT_ON_DEVICE 1
+#else
+#define RT_ON_DEVICE 0
+#endif
+
+struct v3 { float x, y, z; };
+RT_HD v3 mk3(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_HD v3 operator+(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_HD v3 operator-(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_HD v3 operator-(v3 a) { return mk3(-a.x, -a.y, -a.z); }
+RT_HD v3 operator*(float s, v3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+RT_HD v3 operator*(v3 a, v3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_HD float dot3(v3 a, v3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+RT_HD v3 fma3(float s, v3 a, v3 b) { return mk3(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z)); }
+
+RT_HD float rt_nan() { return __builtin_nanf(""); }
+RT_HD float rt_inf() { return __builtin_huge_valf(); }
+RT_HD int f2i(float f) { int i; memcpy(&i, &f, 4); return i; }
+RT_HD float i2f(int i) { float f; memcpy(&f, &i, 4); return f; }
+
+// 1-ulp hardware reciprocal / sqrt on the device (v_rcp_f32, v_sqrt_f32); IEEE on the host.
+RT_HD float rt_rcp(float x) {
+#if RT_ON_DEVICE
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+RT_HD float rt_sqrt(float x) {
+#if RT_ON_DEVICE
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
+// sin and cos of 2*pi*u for u in [0,1): v_sin_f32 / v_cos_f32 take their argument in revolutions.
+RT_HD void rt_sincos_2pi(float u, float* s, float* c) {
+#if RT_ON_DEVICE
+    *s = __builtin_amdgcn_sinf(u);
+    *c = __builtin_amdgcn_cosf(u);
+#else
+    *s = sinf(6.283185307179586f * u);
+    *c = cosf(6.283185307179586f * u);
+#endif
+}
+RT_HD float rt_log10(float x) {
+#if RT_ON_DEVICE
+    return __builtin_amdgcn_logf(x) * 0.30102999566398120f;  // v_log_f32 is log2
+#else
+    return log2f(x) * 0.30102999566398120f;
+#endif
+}
+RT_HD v3 normalize3(v3 a) {
+    float l2 = dot3(a, a);
+    return rt_rcp(rt_sqrt(l2)) * a;
+}
+
+RT_HD rt_f4 ld4(const rt_f4* p) {
+#if RT_ON_DEVICE
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    rt_f4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r;
+#else
+    return *p;
+#endif
+}
+
+// ------------------------------------------------------------------ Philox4x32-10
+// Counter (pixel, sample, bounce, block), key = render seed.  Draw schedule:
+//   bounce 0 / block 0: pixel jitter x, y, lens a, lens b     block 1: shutter time
+//   bounce b / block 0: unit-vector u1, u2, dielectric draw   block 1 + m/4, lane m%4: medium m
+// A draw is the top 24 bits * 2^-24, exactly representable in fp32.
+RT_HD void rt_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        if (r) { k0 += W0; k1 += W1; }
+        uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+RT_HD float rt_u24(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// utils.rs:13-22: the reference normalises its in-ball rejection sample, i.e. it draws a uniform
+// unit vector; this is the direct map with the same distribution.
+RT_HD v3 rt_unit_vector(float u1, float u2) {
+    float z = 1.0f - 2.0f * u1;
+    float r = rt_sqrt(fmaxf(0.0f, 1.0f - z * z));
+    float s, c; rt_sincos_2pi(u2, &s, &c);
+    return mk3(r * c, r * s, z);
+}
+
+// ------------------------------------------------------------------ camera (cameras.rs:82-98)
+RT_HD void rt_camera_ray(const RtCameraDev& cam, const RtFrameDev& fr, uint32_t pixel, uint32_t sample,
+                         v3& o, v3& d, float& time) {
+    uint32_t r0[4], r1[4];
+    rt_philox(pixel, sample, 0u, 0u, fr.key0, fr.key1, r0);
+    rt_philox(pixel, sample, 0u, 1u, fr.key0, fr.key1, r1);
+    int px = (int)(pixel % (uint32_t)fr.width), py = (int)(pixel / (uint32_t)fr.width);
+    int j = fr.height - 1 - py;                                    // main.rs:567,595
+    float s = ((float)px + rt_u24(r0[0])) * fr.inv_wm1;            // main.rs:572
+    float t = ((float)j + rt_u24(r0[1])) * fr.inv_hm1;             // main.rs:573
+    float rad = rt_sqrt(rt_u24(r0[2])), sn, cs;                    // cameras.rs:103-113 (direct disk map)
+    rt_sincos_2pi(rt_u24(r0[3]), &sn, &cs);
+    float dx = cam.lens_radius * rad * cs, dy = cam.lens_radius * rad * sn;
+    v3 U = mk3(cam.u[0], cam.u[1], cam.u[2]), V = mk3(cam.v[0], cam.v[1], cam.v[2]);
+    v3 off = fma3(dx, U, dy * V);
+    time = (cam.shutter_open != 0.0f || cam.shutter_close != 0.0f)
+               ? fmaf(cam.shutter_close - cam.shutter_open, rt_u24(r1[0]), cam.shutter_open) : 0.0f;
+    o = mk3(cam.origin[0], cam.origin[1], cam.origin[2]) + off;
+    v3 H = mk3(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]);
+    v3 Vv = mk3(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
+    d = fma3(s, H, fma3(t, Vv, mk3(cam.dir0[0], cam.dir0[1], cam.dir0[2]))) - off;
+}
+
+// ------------------------------------------------------------------ primitive tests
+// All return the accepted t, or NaN for "no hit in [tmin, tmax]".
+//
+// Sphere (objects.rs:205-239): nearer root if in range, else the farther one.  fp32 cannot afford
+// the reference's half_b^2 - a*c (catastrophic for r = 1000 / 5000), so the discriminant comes from
+// the distance between centre and ray line, and the two roots from q = b' + sign(b') sqrt(a*delta)
+// (Haines et al., "Precision improvements for ray/sphere intersection", Ray Tracing Gems ch. 7).
+// `self` = the ray starts on this very sphere: the roots are then exactly {0, 2b'/a}; the zero
+// root is what the reference discards through t_min = 0.001.
+RT_HD float rt_hit_sphere(v3 c, float r, v3 o, v3 d, float tmin, float tmax, bool self) {
+    v3 f = o - c;
+    float a = dot3(d, d), ia = rt_rcp(a);
+    float bp = -dot3(f, d);
+    if (self) {
+        float t = 2.0f * bp * ia;
+        return (bp > 0.0f && t >= tmin && t <= tmax) ? t : rt_nan();
+    }
+    float cc = fmaf(-r, r, dot3(f, f));
+    float disc;
+    if (fabsf(cc) < 0.125f * r * r) {
+        // Origin within a few percent of the radius from the surface (the r = 1000 ground spheres
+        // seen from a camera 3 units above them): f.f - r^2 and the discriminant cancel in fp32.
+        // Redo the cancelling terms of objects.rs:206-210 in f64 (full-rate FMA on gfx950).
+        double fx = (double)o.x - (double)c.x, fy = (double)o.y - (double)c.y, fz = (double)o.z - (double)c.z;
+        double dx = d.x, dy = d.y, dz = d.z, rr = r;
+        double A = dx * dx + dy * dy + dz * dz;
+        double B = -(fx * dx + fy * dy + fz * dz);
+        double Cc = fx * fx + fy * fy + fz * fz - rr * rr;
+        double D = B * B - A * Cc;
+        if (!(D >= 0.0)) return rt_nan();
+        bp = (float)B; cc = (float)Cc; disc = (float)D;
+    } else {
+        v3 l = fma3(bp * ia, d, f);
+        float delta = fmaf(r, r, -dot3(l, l));
+        if (!(delta >= 0.0f)) return rt_nan();
+        disc = a * delta;
+    }
+    float q = bp + copysignf(rt_sqrt(disc), bp);
+    float ta = q * ia, tb = cc * rt_rcp(q);
+    float tn = fminf(ta, tb), tf = fmaxf(ta, tb);
+    if (tn >= tmin && tn <= tmax) return tn;
+    if (tf >= tmin && tf <= tmax) return tf;
+    return rt_nan();
+}
+
+// Rectangle (objects.rs:384-411).  type 0 = Xy, 1 = Xz, 2 = Yz.  A NaN t (ray inside the plane
+// with a zero direction component) is a miss here; the reference's comparisons let it through.
+RT_HD float rt_hit_rect(rt_f4 r0, float k, int type, v3 o, v3 d, float tmin, float tmax) {
+    float oa, da, ox, dx, oy, dy;
+    if (type == 0) { oa = o.z; da = d.z; ox = o.x; dx = d.x; oy = o.y; dy = d.y; }
+    else if (type == 1) { oa = o.y; da = d.y; ox = o.x; dx = d.x; oy = o.z; dy = d.z; }
+    else { oa = o.x; da = d.x; ox = o.y; dx = d.y; oy = o.z; dy = d.z; }
+    float t = (k - oa) * rt_rcp(da);
+    if (!(t >= tmin && t <= tmax)) return rt_nan();
+    float x = fmaf(t, dx, ox), y = fmaf(t, dy, oy);
+    if (x < r0.x || x > r0.y || y < r0.z || y > r0.w) return rt_nan();
+    return t;
+}
+
+RT_HD v3 rt_msphere_center(rt_f4 m0, rt_f4 m1, rt_f4 m2, float time) {  // objects.rs:285-289
+    float s = (time - m1.w) * m2.x;
+    return mk3(fmaf(s, m1.x, m0.x), fmaf(s, m1.y, m0.y), fmaf(s, m1.z, m0.z));
+}
+
+// Slab test (bvh.rs:46-61) against the interval [tmin, tmax]; returns the entry t or +inf.
+// fminf/fmaxf drop NaNs (0 * inf when a direction component is 0 and the origin lies on the slab
+// plane), which keeps the test conservative.
+RT_HD float rt_slab(float lx, float ly, float lz, float hx, float hy, float hz, v3 o, v3 inv, float tmin, float tmax) {
+    float t0x = (lx - o.x) * inv.x, t1x = (hx - o.x) * inv.x;
+    float t0y = (ly - o.y) * inv.y, t1y = (hy - o.y) * inv.y;
+    float t0z = (lz - o.z) * inv.z, t1z = (hz - o.z) * inv.z;
+    float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+    float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
+    return tn <= tf ? tn : rt_inf();
+}
+
+// ------------------------------------------------------------------ instances (transrot.rs)
+RT_HD v3 rt_to_object_point(rt_f4 i0, rt_f4 i1, v3 p) {
+    return mk3(fmaf(i0.x, p.x, fmaf(-i0.y, p.z, i0.z)), p.y + i0.w, fmaf(i0.y, p.x, fmaf(i0.x, p.z, i1.x)));
+}
+RT_HD v3 rt_to_object_dir(rt_f4 i0, v3 d) {
+    return mk3(fmaf(i0.x, d.x, -i0.y * d.z), d.y, fmaf(i0.y, d.x, i0.x * d.z));
+}
+
+struct RtHit { float t; uint32_t code; int32_t inst; };
+
+// ------------------------------------------------------------------ closest surface hit
+// Stack-based traversal of the two-level BVH; equivalent to bvh.rs:159-187 + objects.rs:67-78
+// (closest hit is independent of tree shape and visiting order, ties aside).  `src` is the hit
+// code of the surface the ray starts on (RT_HIT_NONE for camera rays and medium scatters): a
+// planar primitive can never be re-hit from itself and a sphere only through its far root, which
+// replaces the reference's reliance on f64 round-off staying below t_min.
+// On entry hit.t = tmax, hit.code = RT_HIT_NONE.  Stack: set(i, v) / get(i) on an int array.
+template <class Stack>
+RT_HD void rt_closest_hit(const RtSceneView& sc, v3 wo, v3 wd, float time, float tmin, uint32_t src, Stack& stk, RtHit& hit) {
+    if (sc.root < 0) return;
+    v3 o = wo, d = wd;
+    v3 inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
+    int32_t inst = -1, sp = 0, cur = sc.root;
+    for (;;) {
+        if (cur >= 0) {
+            if (cur >= RT_SENTINEL) {
+                if (cur == RT_EMPTY_STACK) break;
+                o = wo; d = wd; inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z)); inst = -1;  // left the instance
+                cur = sp > 0 ? stk.get(--sp) : RT_EMPTY_STACK;
+                continue;
+            }
+            const rt_f4* n = sc.nodes + 4 * (size_t)cur;
+            rt_f4 q0 = ld4(n), q1 = ld4(n + 1), q2 = ld4(n + 2), q3 = ld4(n + 3);
+            float tl = rt_slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tmin, hit.t);
+            float tr = rt_slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tmin, hit.t);
+            int32_t cl = f2i(q3.x), cr = f2i(q3.y);
+            bool hl = tl < rt_inf(), hr = tr < rt_inf();
+            if (hl && hr) {
+                bool left_first = tl <= tr;
+                if (sp < RT_STACK_DEPTH) stk.set(sp++, left_first ? cr : cl);
+                cur = left_first ? cl : cr;
+            } else if (hl) cur = cl;
+            else if (hr) cur = cr;
+            else cur = sp > 0 ? stk.get(--sp) : RT_EMPTY_STACK;
+            continue;
+        }
+        uint32_t x = ~(uint32_t)cur;
+        if (x & RT_LEAF_INSTANCE_BIT) {
+            int32_t ii = (int32_t)(x & 0x3FFFFFFFu);
+            rt_f4 i0 = ld4(sc.instances + 2 * (size_t)ii), i1 = ld4(sc.instances + 2 * (size_t)ii + 1);
+            if (sp < RT_STACK_DEPTH) stk.set(sp++, RT_SENTINEL);
+            inst = ii;
+            o = rt_to_object_point(i0, i1, wo); d = rt_to_object_dir(i0, wd);
+            inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
+            cur = f2i(i1.y);
+            continue;
+        }
+        uint32_t kind = (x >> 28) & 3u, cnt = ((x >> 26) & 3u) + 1u, first = x & 0x03FFFFFFu;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            uint32_t idx = first + k, code = RT_HIT_CODE(kind, idx);
+            float t;
+            if (kind == RT_KIND_SPHERE) {
+                rt_f4 s = ld4(sc.spheres + idx);
+                t = rt_hit_sphere(mk3(s.x, s.y, s.z), s.w, o, d, tmin, hit.t, code == src);
+            } else if (kind == RT_KIND_RECT) {
+                if (code == src) continue;
+                rt_f4 r0 = ld4(sc.rects + 2 * (size_t)idx), r1 = ld4(sc.rects + 2 * (size_t)idx + 1);
+                t = rt_hit_rect(r0, r1.x, f2i(r1.y), o, d, tmin, hit.t);
+            } else {
+                const rt_f4* m = sc.mspheres + 3 * (size_t)idx;
+                rt_f4 m0 = ld4(m), m1 = ld4(m + 1), m2 = ld4(m + 2);
+                t = rt_hit_sphere(rt_msphere_center(m0, m1, m2, time), m0.w, o, d, tmin, hit.t, code == src);
+            }
+            if (t < hit.t) { hit.t = t; hit.code = code; hit.inst = inst; }  // false for NaN
+        }
+        cur = sp > 0 ? stk.get(--sp) : RT_EMPTY_STACK;
+    }
+}
+
+// ------------------------------------------------------------------ constant media (mediums.rs:39-87)
+// Closest hit of the boundary's primitives inside [tmin, tmax] (linear scan = objects.rs:67-78).
+RT_HD float rt_boundary_hit(const RtSceneView& sc, rt_f4 m2, rt_f4 m3, v3 o, v3 d, float time, float tmin, float tmax) {
+    float best = tmax; bool any = false;
+    int s0 = f2i(m2.y), sn = f2i(m2.z), q0 = f2i(m2.w), qn = f2i(m3.x), r0 = f2i(m3.y), rn = f2i(m3.z);
+    for (int i = 0; i < sn; ++i) {
+        rt_f4 s = ld4(sc.spheres + s0 + i);
+        float t = rt_hit_sphere(mk3(s.x, s.y, s.z), s.w, o, d, tmin, best, false);
+        if (t == t) { best = t; any = true; }
+    }
+    for (int i = 0; i < qn; ++i) {
+        const rt_f4* m = sc.mspheres + 3 * (size_t)(q0 + i);
+        rt_f4 a = ld4(m), b = ld4(m + 1), c = ld4(m + 2);
+        float t = rt_hit_sphere(rt_msphere_center(a, b, c, time), a.w, o, d, tmin, best, false);
+        if (t == t) { best = t; any = true; }
+    }
+    for (int i = 0; i < rn; ++i) {
+        rt_f4 a = ld4(sc.rects + 2 * (size_t)(r0 + i)), b = ld4(sc.rects + 2 * (size_t)(r0 + i) + 1);
+        float t = rt_hit_rect(a, b.x, f2i(b.y), o, d, tmin, best);
+        if (t == t) { best = t; any = true; }
+    }
+    return any ? best : rt_nan();
+}
+
+// Tests every medium against the segment [tmin, hit.t]; a free-flight collision that lands before
+// the current closest hit replaces it.  With one fixed draw per (medium, segment) the outcome does
+// not depend on the order in which the reference's BVH would have visited the medium.
+RT_HD void rt_media_hits(const RtSceneView& sc, v3 wo, v3 wd, float time, float tmin, uint32_t pixel, uint32_t sample,
+                         uint32_t bounce, uint32_t key0, uint32_t key1, RtHit& hit) {
+    uint32_t rnd[4] = {0, 0, 0, 0};
+    float len = rt_sqrt(dot3(wd, wd));
+    for (int m = 0; m < sc.n_media; ++m) {
+        if ((m & 3) == 0) rt_philox(pixel, sample, bounce, 1u + (uint32_t)(m >> 2), key0, key1, rnd);
+        const rt_f4* md = sc.media + 4 * (size_t)m;
+        rt_f4 m0 = ld4(md), m1 = ld4(md + 1);
+        v3 inv = mk3(rt_rcp(wd.x), rt_rcp(wd.y), rt_rcp(wd.z));
+        if (!(rt_slab(m0.x, m0.y, m0.z, m1.x, m1.y, m1.z, wo, inv, tmin, hit.t) < rt_inf())) continue;
+        rt_f4 m2 = ld4(md + 2), m3 = ld4(md + 3);
+        v3 o = wo, d = wd;
+        int ii = f2i(m2.x);
+        if (ii >= 0) {
+            rt_f4 i0 = ld4(sc.instances + 2 * (size_t)ii), i1 = ld4(sc.instances + 2 * (size_t)ii + 1);
+            o = rt_to_object_point(i0, i1, wo); d = rt_to_object_dir(i0, wd);
+        }
+        float t1 = rt_boundary_hit(sc, m2, m3, o, d, time, -rt_inf(), rt_inf());   // mediums.rs:46
+        if (!(t1 == t1)) continue;
+        // mediums.rs:47 asks for the next boundary hit after t1 + 0.0001; in fp32 that offset vanishes once
+        // |t1| exceeds ~1000 (the r = 5000 fog), so it is widened to a few ulps of t1 when larger.
+        float t2 = rt_boundary_hit(sc, m2, m3, o, d, time, t1 + fmaxf(0.0001f, 1e-6f * fabsf(t1)), rt_inf());
+        if (!(t2 == t2)) continue;
+        if (t1 < tmin) t1 = tmin;
+        if (t2 > hit.t) t2 = hit.t;
+        if (t1 >= t2) continue;
+        if (t1 < 0.0f) t1 = 0.0f;
+        float inside = (t2 - t1) * len;
+        float hit_dist = m0.w * rt_log10(rt_u24(rnd[m & 3]));                      // mediums.rs:64 (log base 10)
+        if (hit_dist > inside) continue;
+        float t = t1 + hit_dist * rt_rcp(len);
+        if (t < hit.t) { hit.t = t; hit.code = RT_HIT_CODE(RT_KIND_MEDIUM, (uint32_t)m); hit.inst = -1; }
+    }
+}
+
+// ------------------------------------------------------------------ hit record (objects.rs:126-152)
+struct RtSurface { v3 p, n; int32_t mat, id; bool front; float u, v; };
+
+RT_HD void rt_sphere_uv(v3 n, float* u, float* v) {  // objects.rs:179-193
+    float theta = acosf(-n.y);
+    float phi = atan2f(-n.z, n.x) + 3.14159265358979f;
+    *u = phi * 0.15915494309189535f; *v = theta * 0.3183098861837907f;
+}
+
+RT_HD void rt_surface(const RtSceneView& sc, v3 wo, v3 wd, float time, const RtHit& h, bool want_uv, RtSurface& s) {
+    uint32_t kind = RT_HIT_KIND(h.code), idx = RT_HIT_INDEX(h.code);
+    s.u = 0.0f; s.v = 0.0f;
+    if (kind == RT_KIND_MEDIUM) {  // mediums.rs:69-80
+        const rt_f4* md = sc.media + 4 * (size_t)idx;
+        s.p = fma3(h.t, wd, wo);
+        s.front = wd.x < 0.0f;
+        s.n = mk3(s.front ? 1.0f : -1.0f, 0.0f, 0.0f);
+        s.mat = f2i(ld4(md + 1).w); s.id = f2i(ld4(md + 3).w);
+        return;
+    }
+    v3 o = wo, d = wd;
+    rt_f4 i0, i1;
+    if (h.inst >= 0) {
+        i0 = ld4(sc.instances + 2 * (size_t)h.inst); i1 = ld4(sc.instances + 2 * (size_t)h.inst + 1);
+        o = rt_to_object_point(i0, i1, wo); d = rt_to_object_dir(i0, wd);
+    }
+    v3 p = fma3(h.t, d, o), on;
+    rt_i2 meta;
+    if (kind == RT_KIND_SPHERE) {
+        rt_f4 sp = ld4(sc.spheres + idx);
+        on = normalize3(rt_rcp(sp.w) * (p - mk3(sp.x, sp.y, sp.z)));  // objects.rs:226
+        meta = sc.sphere_meta[idx];
+        if (want_uv) rt_sphere_uv(on, &s.u, &s.v);
+    } else if (kind == RT_KIND_MSPHERE) {
+        const rt_f4* m = sc.mspheres + 3 * (size_t)idx;
+        rt_f4 m0 = ld4(m), m1 = ld4(m + 1), m2 = ld4(m + 2);
+        on = normalize3(rt_rcp(m0.w) * (p - rt_msphere_center(m0, m1, m2, time)));  // objects.rs:313
+        meta = sc.msphere_meta[idx];
+        if (want_uv) rt_sphere_uv(on, &s.u, &s.v);
+    } else {
+        rt_f4 r0 = ld4(sc.rects + 2 * (size_t)idx), r1 = ld4(sc.rects + 2 * (size_t)idx + 1);
+        int type = f2i(r1.y);
+        on = type == 0 ? mk3(0, 0, 1) : (type == 1 ? mk3(0, 1, 0) : mk3(1, 0, 0));  // objects.rs:385-389
+        meta = sc.rect_meta[idx];
+        if (want_uv) {
+            float x = type == 2 ? p.y : p.x, y = type == 0 ? p.y : p.z;
+            s.u = (x - r0.x) * rt_rcp(r0.y - r0.x); s.v = (y - r0.z) * rt_rcp(r0.w - r0.z);  // objects.rs:399-400
+        }
+    }
+    bool front = dot3(d, on) < 0.0f;          // objects.rs:137
+    v3 n = front ? on : -on;
+    if (h.inst >= 0) {
+        // Unwind the Translate / RotateY chain innermost first (transrot.rs:28-31, 104-115).  RotateY
+        // rebuilds the record from the ray on its inner side and the rotated, already flipped normal.
+        int first = f2i(i1.z), count = f2i(i1.w);
+        for (int k = count - 1; k >= 0; --k) {
+            rt_f4 op = ld4(sc.ops + first + k);
+            if (f2i(op.w) == RT_OP_TRANSLATE) { p = p + mk3(op.x, op.y, op.z); continue; }
+            float c = op.x, sn = op.y;
+            p = mk3(fmaf(c, p.x, sn * p.z), p.y, fmaf(-sn, p.x, c * p.z));
+            v3 nw = mk3(fmaf(c, n.x, sn * n.z), n.y, fmaf(-sn, n.x, c * n.z));
+            front = dot3(d, nw) < 0.0f;
+            n = front ? nw : -nw;
+            d = mk3(fmaf(c, d.x, sn * d.z), d.y, fmaf(-sn, d.x, c * d.z));
+        }
+    }
+    s.p = p; s.n = n; s.front = front; s.mat = meta.x; s.id = meta.y;
+}
+
+// ------------------------------------------------------------------ textures (textures.rs)
+RT_HD float rt_perlin_noise(const rt_f4* vec, const uint8_t* perm, v3 p) {  // textures.rs:146-170, 214-237
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    float uu = u * u * (3.0f - 2.0f * u), vv = v * v * (3.0f - 2.0f * v), ww = w * w * (3.0f - 2.0f * w);
+    float accum = 0.0f;
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj)
+#pragma unroll
+            for (int dk = 0; dk < 2; ++dk) {
+                int h = perm[(i + di) & 255] ^ perm[256 + ((j + dj) & 255)] ^ perm[512 + ((k + dk) & 255)];
+                rt_f4 c = ld4(vec + h);
+                float wgt = (di ? uu : 1.0f - uu) * (dj ? vv : 1.0f - vv) * (dk ? ww : 1.0f - ww);
+                accum = fmaf(wgt, fmaf(c.x, u - (float)di, fmaf(c.y, v - (float)dj, c.z * (w - (float)dk))), accum);
+            }
+    return accum;
+}
+RT_HD float rt_turbulence(const rt_f4* vec, const uint8_t* perm, v3 p) {  // textures.rs:131-143
+    float accum = 0.0f, weight = 1.0f;
+    for (int i = 0; i < 7; ++i) { accum = fmaf(weight, rt_perlin_noise(vec, perm, p), accum); weight *= 0.5f; p = 2.0f * p; }
+    return fabsf(accum);
+}
+RT_HD v3 rt_texture_value(const RtSceneView& sc, int tex, v3 p) {
+    for (int it = 0; it < 16; ++it) {
+        rt_f4 t0 = ld4(sc.textures + 2 * (size_t)tex), t1 = ld4(sc.textures + 2 * (size_t)tex + 1);
+        int type = f2i(t0.x);
+        if (type == RT_TEX_CHECKER) {  // textures.rs:60-69
+            float sines = sinf(10.0f * p.x) * sinf(10.0f * p.y) * sinf(10.0f * p.z);
+            tex = sines < 0.0f ? f2i(t0.z) : f2i(t0.y);
+            continue;
+        }
+        if (type == RT_TEX_NOISE) {  // textures.rs:87-96
+            int table = f2i(t0.y);
+            float turb = rt_turbulence(sc.perlin_vec + (size_t)table * RT_PERLIN_VEC_F4,
+                                       sc.perlin_perm + (size_t)table * RT_PERLIN_PERM_BYTES, t1.x * p);
+            float s = 0.5f * (1.0f + sinf(fmaf(10.0f, turb, t1.x * p.z)));
+            return mk3(s, s, s);
+        }
+        return mk3(t1.x, t1.y, t1.z);  // textures.rs:28-32
+    }
+    return mk3(0, 0, 0);
+}
+
+// ------------------------------------------------------------------ materials (materials.rs)
+RT_HD v3 rt_reflect(v3 v, v3 n) { return fma3(-2.0f * dot3(v, n), n, v); }  // utils.rs:87-89
+
+// One scatter event (lib.rs:64-65).  u1,u2: unit-vector draws, u3: dielectric draw.
+// Returns true when the path continues along `dir` with throughput *= atten.
+RT_HD bool rt_scatter(const RtSceneView& sc, const RtSurface& s, v3 wd, float u1, float u2, float u3,
+                      v3& atten, v3& dir, v3& emitted) {
+    rt_f4 a0 = ld4(sc.materials + 2 * (size_t)s.mat);
+    int type = f2i(a0.x), tex = f2i(a0.y);
+    emitted = mk3(0, 0, 0);
+    atten = mk3(1, 1, 1);
+    dir = s.n;
+    if (type == RT_MAT_LAMBERTIAN) {  // materials.rs:77-90
+        dir = s.n + rt_unit_vector(u1, u2);
+        if (dot3(dir, dir) < 1e-16f) dir = s.n;
+        atten = rt_texture_value(sc, tex, s.p);
+        return true;
+    }
+    if (type == RT_MAT_METAL) {  // materials.rs:129-145
+        rt_f4 a1 = ld4(sc.materials + 2 * (size_t)s.mat + 1);
+        dir = fma3(a0.z, rt_unit_vector(u1, u2), rt_reflect(normalize3(wd), s.n));
+        atten = mk3(a1.x, a1.y, a1.z);
+        return dot3(dir, s.n) > 0.0f;
+    }
+    if (type == RT_MAT_DIELECTRIC) {  // materials.rs:181-209
+        float ratio = s.front ? rt_rcp(a0.w) : a0.w;
+        v3 ud = normalize3(wd);
+        float cos_theta = -fminf(dot3(ud, s.n), 1.0f);
+        float sin_theta = rt_sqrt(fmaxf(0.0f, 1.0f - cos_theta * cos_theta));
+        bool cannot = ratio * sin_theta > 1.0f;
+        float r0 = (1.0f - ratio) * rt_rcp(1.0f + ratio); r0 *= r0;  // materials.rs:174-178
+        float om = 1.0f - cos_theta, om2 = om * om;
+        float refl = fmaf(1.0f - r0, om2 * om2 * om, r0);
+        if (cannot || refl > u3) dir = rt_reflect(ud, s.n);
+        else {  // utils.rs:79-84
+            v3 perp = ratio * fma3(cos_theta, s.n, ud);
+            float par = -rt_sqrt(fabsf(1.0f - dot3(perp, perp)));
+            dir = fma3(par, s.n, perp);
+        }
+        return true;
+    }
+    if (type == RT_MAT_LIGHT) {  // materials.rs:243-249
+        emitted = rt_texture_value(sc, tex, s.p);
+        return false;
+    }
+    // Isotropic, materials.rs:276-283
+    dir = rt_unit_vector(u1, u2);
+    atten = rt_texture_value(sc, tex, s.p);
+    return true;
+}
