@@ -1,0 +1,178 @@
+"""Host logic that needs no GPU: the YAML-subset config reader (main.rs:453-494), the canned scenes'
+construction order, and the C ABI surface (every symbol include/rt_hip.h declares must be exported)."""
+import os
+import re
+import tempfile
+
+import numpy as np
+import pytest
+
+import ray_tracing_amd as rt
+from helpers import CONFIGS, ROOT, SCENE_SEED, OracleBuilder, scene_pair
+
+# The layout the reference's own config files use (block mappings, one key per line).
+BLOCK_STYLE = """image_width: 600
+samples_per_pixel: 200
+max_depth: 50
+camera:
+  look_from:
+    x: 278.0
+    y: 278.0
+    z: -800.0
+  look_at:
+    x: 278.0
+    y: 278.0
+    z: 0.0
+  v_up:
+    x: 0.0
+    y: 1.0
+    z: 0.0
+  vertical_fov_deg: 40.0
+  aspect_ratio: 1.0
+  aperture: 0.1
+  focus_distance: 10.0
+scene:
+  type: CornellSmoke
+"""
+LEGACY = """image_width: 640
+samples_per_pixel: 50
+max_depth: 20
+camera:
+  look_from: {x: 0.0, y: 0.0, z: 10.0}
+  look_at: {x: 0.0, y: 0.0, z: 0.0}
+  v_up: {x: 0.0, y: 1.0, z: 0.0}
+  vertical_fov_deg: 20.0
+  aspect_ratio: 1.25
+  aperture: 0.1
+  focus_distance: 10.0
+objects:
+  objects:
+  - center:
+      x: 0.0
+      y: -100.5
+      z: -1.0
+    radius: 100.0
+    material:
+      type: Lambertian
+      albedo:
+        x: 0.8
+        y: 0.8
+        z: 0.0
+  # a comment between items
+  - center:
+      x: -1.0
+      y: 0.0
+      z: -1.0
+    radius: -0.4
+    material:
+      type: Dielectric
+      ir: 1.5
+  - center:
+      x: 1.0
+      y: 0.0
+      z: -1.0
+    radius: 0.5
+    material:
+      type: Metal
+      albedo:
+        x: 0.8
+        y: 0.6
+        z: 0.2
+      fuzz: 0.2
+"""
+
+
+def load_text(text):
+    with tempfile.NamedTemporaryFile("w", suffix=".yml", delete=False) as f:
+        f.write(text)
+    try:
+        return rt.load_config(f.name), f.name
+    finally:
+        pass
+
+
+def test_block_style_config():
+    cfg, path = load_text(BLOCK_STYLE)
+    assert (cfg.image_width, cfg.image_height, cfg.samples_per_pixel, cfg.max_depth) == (600, 600, 200, 50)
+    assert list(cfg.look_from) == [278.0, 278.0, -800.0] and list(cfg.look_at) == [278.0, 278.0, 0.0] and list(cfg.v_up) == [0, 1, 0]
+    assert (cfg.vertical_fov_deg, cfg.aspect_ratio, cfg.aperture, cfg.focus_distance) == (40.0, 1.0, 0.1, 10.0)
+    assert cfg.scene_type == b"CornellSmoke"
+    os.unlink(path)
+
+
+def test_legacy_objects_schema_is_a_list_scene():
+    cfg, path = load_text(LEGACY)
+    assert cfg.scene_type == b"List" and cfg.n_list_objects == 3 and cfg.image_height == 512
+    b = rt.Builder()
+    w = b.scene_from_config(path, SCENE_SEED)
+    info = b.flatten_info(w)
+    assert info.n_spheres == 3 and info.n_objects == 3 and info.n_materials == 3
+    os.unlink(path)
+
+
+def test_defaults_and_errors():
+    # main.rs:468-480: width 400, spp 500, depth 50 when absent
+    body = BLOCK_STYLE.split("camera:")[1]
+    cfg, path = load_text("camera:" + body)
+    assert (cfg.image_width, cfg.samples_per_pixel, cfg.max_depth, cfg.image_height) == (400, 500, 50, 400)
+    os.unlink(path)
+    for bad, why in [(BLOCK_STYLE.replace("  aperture: 0.1\n", ""), "camera"),              # cameras.rs:10-18: all 7 required
+                     (BLOCK_STYLE.replace("CornellSmoke", "Teapot"), "unknown scene type"),
+                     (BLOCK_STYLE.replace("scene:\n  type: CornellSmoke\n", ""), "scene"),
+                     (BLOCK_STYLE.replace("image_width: 600", "image_width: -3"), "image_width"),
+                     (BLOCK_STYLE.replace("  look_at:", "   look_at:"), "Could not read values")]:
+        with pytest.raises(rt.RtError) as e:
+            load_text(bad)
+        assert e.value.code == -7 and "Could not read values" in str(e.value) and why in str(e.value)
+    with pytest.raises(rt.RtError) as e:
+        rt.load_config("/nonexistent/cfg.yml")
+    assert "Could not open config file." in str(e.value)            # main.rs:511
+
+
+def test_shipped_configs_match_the_reference_digest():
+    want = {"cfg.yml": (400, 320, 100, 50, b"TwoPerlinSpheres"), "rectangle.yml": (400, 320, 400, 50, b"SimpleLight"),
+            "orig_img.yml": (640, 512, 50, 20, b"List"), "cornell.yml": (600, 600, 200, 50, b"CornellSmoke"),
+            "final_scene.yml": (800, 800, 100000, 50, b"FinalScene")}
+    for name, (w, h, spp, depth, scene) in want.items():
+        c = rt.load_config(os.path.join(CONFIGS, name))
+        assert (c.image_width, c.image_height, c.samples_per_pixel, c.max_depth, c.scene_type) == (w, h, spp, depth, scene)
+        assert c.aperture == 0.1 and c.focus_distance == 10.0 and list(c.v_up) == [0, 1, 0]
+
+
+def test_canned_scenes_assign_the_same_ids_as_the_oracle():
+    counts = {"cfg.yml": 2, "rectangle.yml": 3, "two_spheres.yml": 2, "cornell_box.yml": 18, "cornell.yml": 20, "final_scene.yml": 3411}
+    for name, n in counts.items():
+        cfg, cam, b, world, ob = scene_pair(name)
+        assert b.object_count() == ob.object_count() == n
+    cfg, cam, b, world, ob = scene_pair("random.yml")
+    assert b.object_count() == ob.object_count() and 400 < b.object_count() <= 488
+    with pytest.raises(rt.RtError):
+        rt.Builder().canned_scene("Teapot", 1)
+
+
+def test_every_declared_symbol_is_exported():
+    header = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    names = set(re.findall(r"\b(rtb?_[a-z0-9_]+)\s*\(", header))
+    assert len(names) >= 35
+    lib = rt.lib()
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert names == set(rt.API), names ^ set(rt.API)                # the Python binding covers exactly the header
+
+
+def test_builder_rejects_bad_handles():
+    b = rt.Builder()
+    for fn in (lambda: b.lambertian_from_texture(99), lambda: b.sphere((0, 0, 0), 1, 42), lambda: b.translate(7, (0, 0, 0)),
+               lambda: b.checker(0, 1), lambda: b.constant_medium(3, 0.1, 0), lambda: b.bvh_node(b.list([]))):
+        with pytest.raises(rt.RtError):
+            fn()
+    with pytest.raises(rt.RtError):
+        b.rectangle(b.lambertian((1, 1, 1)), 0, 1, 0, 1, 0, 5)
+
+
+def test_tonemap_matches_utils_rs():  # utils.rs:49-63
+    spp = 16
+    acc = np.array([[0.25 * spp, 1.0 * spp, 0.0], [4.0 * spp, -1.0, 0.5 * spp]], dtype=np.float32)
+    rgb = rt.tonemap_u8(acc, spp)
+    assert rgb.tolist() == [[128, 255, 0], [255, 0, int(256 * np.sqrt(0.5))]]

@@ -1,0 +1,152 @@
+"""Structural checks of the flattener and BVH builder on the CPU (no GPU): every primitive is reachable exactly once,
+child boxes contain their content, leaves are homogeneous, and the traversal stack bound holds."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ray_tracing_amd as rt
+from helpers import FlatScene, scene_pair
+
+LEAF_INST = 0x40000000
+
+
+def arrays(flat):
+    ptrs = (C.c_void_p * 14).from_address(flat.view)
+    ints = (C.c_int32 * 12).from_address(flat.view + 14 * 8)
+    (root, n_nodes, n_sph, n_msph, n_rect, n_inst, n_ops, n_media, n_mat, n_tex, n_perlin, max_stack) = list(ints)
+
+    def f4(i, n):
+        if n == 0 or not ptrs[i]:
+            return np.zeros((0, 4), np.float32)
+        return np.ctypeslib.as_array((C.c_float * (4 * n)).from_address(ptrs[i])).reshape(-1, 4).copy()
+
+    def i2(i, n):
+        if n == 0 or not ptrs[i]:
+            return np.zeros((0, 2), np.int32)
+        return np.ctypeslib.as_array((C.c_int32 * (2 * n)).from_address(ptrs[i])).reshape(-1, 2).copy()
+    return dict(root=root, max_stack=max_stack, nodes=f4(0, 4 * n_nodes).reshape(-1, 16), spheres=f4(1, n_sph), sphere_meta=i2(2, n_sph),
+                mspheres=f4(3, 3 * n_msph).reshape(-1, 12), msphere_meta=i2(4, n_msph), rects=f4(5, 2 * n_rect).reshape(-1, 8),
+                rect_meta=i2(6, n_rect), instances=f4(7, 2 * n_inst).reshape(-1, 8), media=f4(9, 4 * n_media).reshape(-1, 16))
+
+
+def prim_box(a, kind, i):
+    if kind == 0:
+        c, r = a["spheres"][i, :3].astype(np.float64), abs(float(a["spheres"][i, 3]))
+        return c - r, c + r
+    if kind == 1:
+        m = a["mspheres"][i].astype(np.float64)
+        c0, r, dc, t0, inv = m[0:3], abs(m[3]), m[4:7], m[7], m[8]
+        cs = [c0 + (t - t0) * inv * dc for t in (0.0, 1.0)]
+        return np.minimum(cs[0], cs[1]) - r, np.maximum(cs[0], cs[1]) + r
+    x0, x1, y0, y1, k = a["rects"][i, :5].astype(np.float64)
+    t = int(a["rects"][i, 5:6].view(np.int32)[0])
+    lo, hi = {0: ((x0, y0, k), (x1, y1, k)), 1: ((x0, k, y0), (x1, k, y1)), 2: ((k, x0, y0), (k, x1, y1))}[t]
+    return np.array(lo), np.array(hi)
+
+
+def walk(a, node, seen, depth, stats, in_blas):
+    n = a["nodes"][node]
+    kids = n[12:14].view(np.int32)
+    boxes = [(n[[0, 1, 2]], n[[3, 4, 5]]), (n[[6, 7, 8]], n[[9, 10, 11]])]
+    stats["depth"] = max(stats["depth"], depth + 1)
+    out_lo, out_hi = np.full(3, np.inf), np.full(3, -np.inf)
+    for (lo, hi), c in zip(boxes, kids):
+        lo, hi = lo.astype(np.float64), hi.astype(np.float64)
+        if c >= 0:
+            clo, chi = walk(a, int(c), seen, depth + 1, stats, in_blas)
+        else:
+            x = ~int(c) & 0x7FFFFFFF
+            if x & LEAF_INST:
+                assert not in_blas, "instances may only appear in the top level"
+                ii = x & 0x3FFFFFFF
+                stats["inst"].append(ii)
+                inst = a["instances"][ii]
+                root = int(inst[5:6].view(np.int32)[0])
+                sub = dict(depth=0, inst=[])
+                walk(a, root, seen, 0, sub, True)
+                stats["blas_depth"] = max(stats.get("blas_depth", 0), sub["depth"])
+                clo, chi = lo, hi       # world box of an instance is checked by the oracle-bbox test below
+            else:
+                kind, cnt, first = (x >> 28) & 3, ((x >> 26) & 3) + 1, x & 0x03FFFFFF
+                assert 1 <= cnt <= 4
+                clo, chi = np.full(3, np.inf), np.full(3, -np.inf)
+                for i in range(first, first + cnt):
+                    assert (kind, i) not in seen or node == 0, "primitive referenced twice"
+                    seen.add((kind, i))
+                    plo, phi = prim_box(a, kind, i)
+                    clo, chi = np.minimum(clo, plo), np.maximum(chi, phi)
+        assert np.all(lo <= clo + 1e-3 * (1 + np.abs(clo))) and np.all(hi >= chi - 1e-3 * (1 + np.abs(chi))), (node, lo, clo, hi, chi)
+        out_lo, out_hi = np.minimum(out_lo, lo), np.maximum(out_hi, hi)
+    return out_lo, out_hi
+
+
+@pytest.mark.parametrize("name", ["orig_img.yml", "rectangle.yml", "random.yml", "cornell_box.yml", "cornell.yml", "final_scene.yml"])
+def test_bvh_invariants(name):
+    cfg, cam, b, world, ob = scene_pair(name)
+    flat = FlatScene(b, world)
+    a = arrays(flat)
+    info = flat.info()
+    seen, stats = set(), dict(depth=0, inst=[])
+    walk(a, a["root"], seen, 0, stats, False)
+    # media boundary primitives are outside the BVH; everything else is referenced exactly once
+    n_bound = {0: 0, 1: 0, 2: 0}
+    for m in a["media"]:
+        iv = m.view(np.int32)
+        n_bound[0] += iv[10]; n_bound[1] += iv[12]; n_bound[2] += iv[14]
+    assert len([s for s in seen if s[0] == 0]) == info.n_spheres - n_bound[0]
+    assert len([s for s in seen if s[0] == 1]) == info.n_moving_spheres - n_bound[1]
+    assert len([s for s in seen if s[0] == 2]) == info.n_rects - n_bound[2]
+    assert stats["depth"] == info.tlas_depth and stats.get("blas_depth", 0) == info.blas_depth
+    assert info.max_stack <= 32 and info.max_stack == info.tlas_depth + (1 + info.blas_depth if info.n_instances and stats["inst"] else 0) or info.max_stack <= 32
+    ids = np.concatenate([a["sphere_meta"][:, 1], a["msphere_meta"][:, 1], a["rect_meta"][:, 1], a["media"].view(np.int32)[:, 15]])
+    assert sorted(ids.tolist()) == list(range(info.n_objects))     # creation-order ids, each exactly once
+
+
+def test_world_box_matches_oracle():
+    import helpers
+    for name in ["cornell_box.yml", "final_scene.yml", "random.yml"]:
+        cfg, cam, b, world, ob = scene_pair(name)
+        info = FlatScene(b, world).info()
+        out = (C.c_double * 6)()
+        assert helpers.oracle().orc_world_bbox(ob.h, out) == 0
+        want = np.array(out[:])
+        got = np.array(list(info.world_box))
+        if name == "final_scene.yml":   # the oracle's world box also holds the media (r = 5000 fog); the BVH holds surfaces only
+            assert np.all(got[:3] >= want[:3] - 1e-2) and np.all(got[3:] <= want[3:] + 1e-2)
+        else:
+            assert np.allclose(got, want, atol=2e-3, rtol=1e-6), (name, got, want)
+
+
+def test_single_object_and_empty_world():
+    b = rt.Builder()
+    w = b.list([b.sphere((0, 0, 0), 1.0, b.lambertian((1, 1, 1)))])
+    info = b.flatten_info(w)
+    assert info.n_nodes == 1 and info.tlas_depth == 1 and info.n_spheres == 1
+    info = b.flatten_info(b.list([]))               # nothing to hit: every ray returns the background
+    assert info.n_nodes == 0 and info.max_stack == 0
+
+
+def test_deep_scene_respects_the_stack_budget():
+    rng = np.random.default_rng(5)
+    b = rt.Builder()
+    m = b.lambertian((0.5, 0.5, 0.5))
+    # pathological for SAH: exponentially spaced spheres make very unbalanced splits
+    kids = [b.sphere((float(2.0 ** (i / 40.0)), 0.0, float(rng.normal())), 0.01, m) for i in range(3000)]
+    info = b.flatten_info(b.list(kids))
+    assert info.n_spheres == 3000 and info.max_stack <= 30
+
+
+def test_nested_transforms_and_unsupported_trees():
+    b = rt.Builder()
+    m = b.lambertian((1, 1, 1))
+    inner = b.rotate_y(b.box((0, 0, 0), (1, 1, 1), m), 30.0)
+    outer = b.translate(b.rotate_y(b.list([inner, b.sphere((3, 0, 0), 0.5, m)]), -10.0), (5, 0, 0))
+    info = b.flatten_info(b.list([outer]))
+    assert info.n_instances == 2 and info.n_rects == 6 and info.n_spheres == 1
+    med = b.constant_medium_from_color(b.sphere((0, 0, 0), 1, m), 0.1, (1, 1, 1))
+    with pytest.raises(rt.RtError):                  # a medium as (part of) another medium's boundary
+        b.flatten_info(b.list([b.constant_medium_from_color(med, 0.1, (1, 1, 1))]))
+    with pytest.raises(rt.RtError) as e:             # empty boundary has no bounding box (bvh.rs:140)
+        b.flatten_info(b.list([b.constant_medium_from_color(b.list([]), 0.1, (1, 1, 1))]))
+    assert e.value.code == -5

@@ -1,0 +1,91 @@
+"""Size-independent properties at the image sizes of the headline configs (cornell.yml 600x600, final_scene.yml
+800x800, a 200k-sphere synthetic scene): determinism, sample-range additivity (what multi-GPU sharding relies on),
+independence from the pass size, ray accounting, and the device-buffer entry point."""
+import os
+
+import numpy as np
+import pytest
+
+import ray_tracing_amd as rt
+from helpers import CONFIGS, RENDER_SEED, SCENE_SEED, OracleBuilder, OracleCamera, config_camera, oracle_trace_primary, primary_agreement
+
+pytestmark = pytest.mark.gpu
+
+
+def load(name):
+    cfg, cam = config_camera(name)
+    b = rt.Builder()
+    return cfg, cam, rt.Scene(b, b.scene_from_config(os.path.join(CONFIGS, name), SCENE_SEED), 0)
+
+
+@pytest.mark.parametrize("name,spp", [("cornell.yml", 8), ("final_scene.yml", 6)])
+def test_full_size_properties(gpu_required, name, spp):
+    cfg, cam, scene = load(name)
+    W, H, D = cfg.image_width, cfg.image_height, cfg.max_depth
+    full, sq, st = scene.render(cam, rt.render_params(W, H, spp, D, RENDER_SEED), want_sumsq=True)
+    again, _, st2 = scene.render(cam, rt.render_params(W, H, spp, D, RENDER_SEED))
+    assert np.array_equal(full, again) and st.rays == st2.rays                        # deterministic, bit for bit
+    # ray accounting: every path casts a camera ray; bounces only lose rays; at most max_depth segments per path (lib.rs:58-60)
+    rpb = np.array(list(st.rays_per_bounce[:D]), dtype=np.int64)
+    assert rpb[0] == W * H * spp == st.paths and np.all(np.diff(rpb) <= 0) and rpb.sum() == st.rays <= st.paths * D
+    assert np.isfinite(full).all() and full.min() >= 0 and 0.05 < full.mean() / spp < 5.0
+    assert np.all(sq >= 0) and np.all(sq * spp >= full * full * (1 - 1e-4) - 1e-3)     # Cauchy-Schwarz per pixel
+    # sample ranges add up: [0, k) + [k, spp) is the same set of paths as [0, spp)  -> multi-GPU sample sharding
+    k = spp // 2
+    parts = np.zeros_like(full)
+    _, _, sa = scene.render(cam, rt.render_params(W, H, k, D, RENDER_SEED, sample_offset=0), accum=parts)
+    _, _, sb = scene.render(cam, rt.render_params(W, H, spp - k, D, RENDER_SEED, sample_offset=k), accum=parts)
+    assert sa.rays + sb.rays == st.rays
+    assert np.allclose(parts, full, rtol=2e-6, atol=1e-5)
+    # pass size only changes how the work is cut, not which paths are traced
+    small, _, ss = scene.render(cam, rt.render_params(W, H, spp, D, RENDER_SEED, paths_per_pass=W * H * 2))
+    assert ss.rays == st.rays and ss.passes > st.passes and np.allclose(small, full, rtol=2e-6, atol=1e-5)
+    # a different seed is a different image with the same statistics
+    other, _, _ = scene.render(cam, rt.render_params(W, H, spp, D, RENDER_SEED + 1))
+    assert not np.array_equal(other, full) and abs(other.mean() - full.mean()) < 0.05 * full.mean()
+    scene.close()
+
+
+def test_device_buffer_entry_point_matches_host_one(gpu_required):
+    import torch
+    cfg, cam, scene = load("cornell.yml")
+    W, H = 200, 200
+    p = rt.render_params(W, H, 4, cfg.max_depth, RENDER_SEED, flags=rt.RT_FLAG_SUMSQ)
+    host, host_sq, st = scene.render(cam, rt.render_params(W, H, 4, cfg.max_depth, RENDER_SEED), want_sumsq=True)
+    acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    sq = torch.zeros_like(acc)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        st2 = scene.render_device(cam, p, acc.data_ptr(), sq.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    assert st2.rays == st.rays and np.array_equal(acc.cpu().numpy(), host) and np.array_equal(sq.cpu().numpy(), host_sq)
+    st3 = scene.render_device(cam, p, acc.data_ptr(), sq.data_ptr(), None)           # adds into the same buffers
+    assert np.allclose(acc.cpu().numpy(), 2 * host, rtol=1e-6)
+    scene.close()
+
+
+def test_deep_bvh_synthetic_spheres(gpu_required):
+    """200k random spheres (the shape of the 1M-sphere stress config, scaled to build quickly from Python): primary hits against the oracle."""
+    rng = np.random.default_rng(4)
+    n = 200000
+    cx, cz, cy, rr = rng.uniform(-300, 300, n), rng.uniform(-300, 300, n), rng.uniform(0, 60, n), rng.uniform(0.2, 2.0, n)
+    b, ob = rt.Builder(), OracleBuilder()
+    worlds = []
+    for bb in (b, ob):
+        mats = [bb.lambertian((0.5, 0.5, 0.5)), bb.metal((0.8, 0.8, 0.8), 0.1), bb.dielectric(1.5)]
+        kids = [bb.sphere((0, -1e5, 0), 1e5, mats[0])] + [bb.sphere((cx[i], cy[i], cz[i]), rr[i], mats[0 if i % 20 < 16 else (1 if i % 20 < 19 else 2)]) for i in range(n)]
+        worlds.append(bb.list(kids))
+    ob.set_world(worlds[1])
+    scene = rt.Scene(b, worlds[0], 0)
+    info = scene.info()
+    assert info.n_spheres == n + 1 and info.max_stack <= 32
+    cam = rt.make_camera((0, 120, 420), (0, 20, 0), (0, 1, 0), 40.0, 16 / 9, 0.1, 10.0)
+    W, H = 480, 270
+    p = rt.render_params(W, H, 1, 50, RENDER_SEED)
+    g = scene.trace_primary(cam, p, 0)
+    o = oracle_trace_primary(ob, OracleCamera(cam), W, H, 0, RENDER_SEED)
+    agree, rel = primary_agreement(g, o)
+    assert agree >= 0.9999 and rel <= 1e-4, (agree, rel)
+    accum, _, st = scene.render(cam, rt.render_params(W, H, 4, 50, RENDER_SEED, background=(0.7, 0.8, 1.0)))
+    assert np.isfinite(accum).all() and st.rays > W * H * 4
+    scene.close()

@@ -1,0 +1,313 @@
+"""Known-answer tests that pin the CPU oracle.  The reference ships no tests or fixtures, so these
+vectors are derived by hand from the cited formulas (src/... file:line in each test)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import ray_tracing_amd as rt
+from helpers import OracleBuilder, OracleCamera, RENDER_SEED, d3, oracle
+
+
+def hit(ob, o, d, time=0.0, tmin=0.001, tmax=1e308, pixel=0, sample=0, bounce=1):
+    out = (C.c_double * 10)()
+    i = oracle().orc_hit(ob.h, d3(o), d3(d), time, tmin, tmax, pixel, sample, bounce, RENDER_SEED, out)
+    return i, dict(t=out[0], p=np.array(out[1:4]), n=np.array(out[4:7]), front=out[7] == 1.0, u=out[8], v=out[9])
+
+
+def test_philox_random123_vectors():
+    # Philox4x32-10 known answers of the Random123 distribution (kat_vectors).
+    L = oracle()
+    out = (C.c_uint32 * 4)()
+    cases = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+             ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+             ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in cases:
+        L.orc_philox((C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), out)
+        assert tuple(out) == want
+
+
+def test_draw_is_24_bit_and_in_unit_interval():
+    L = oracle()
+    xs = np.array([L.orc_xi(p, s, RENDER_SEED, b, d) for p in range(5) for s in range(3) for b in range(3) for d in range(6)])
+    assert xs.min() >= 0.0 and xs.max() < 1.0
+    assert np.all(xs * 2 ** 24 == np.floor(xs * 2 ** 24))          # exactly representable in fp32
+    assert abs(xs.mean() - 0.5) < 0.08 and len(np.unique(xs)) == len(xs)
+
+
+def test_scene_rng_is_splitmix64():
+    # SplitMix64 reference outputs for seed 0: 0xe220a8397b1dcdaf, 0x6e789e6aa1b965f4, 0x06c45d188009454f
+    out = (C.c_double * 3)()
+    oracle().orc_scene_rng(0, 3, out)
+    want = [0xe220a8397b1dcdaf, 0x6e789e6aa1b965f4, 0x06c45d188009454f]
+    assert [int(x * 2 ** 53) for x in out] == [w >> 11 for w in want]
+
+
+def test_kat1_sphere_hit():  # objects.rs:205-239 ; agrees with the uv table at objects.rs:185
+    ob = OracleBuilder()
+    ob.set_world(ob.list([ob.sphere((0, 0, -1), 0.5, ob.lambertian((0.5, 0.5, 0.5)))]))
+    i, h = hit(ob, (0, 0, 0), (0, 0, -1))
+    assert i == 0 and h["t"] == pytest.approx(0.5, abs=1e-15)
+    assert np.allclose(h["p"], (0, 0, -0.5)) and np.allclose(h["n"], (0, 0, 1)) and h["front"]
+    assert (h["u"], h["v"]) == pytest.approx((0.25, 0.5))
+    # from inside: farther root, normal flipped against the ray (objects.rs:137-141)
+    i, h = hit(ob, (0, 0, -1), (0, 0, -1))
+    assert h["t"] == pytest.approx(0.5) and np.allclose(h["n"], (0, 0, 1)) and not h["front"]
+    # un-normalised direction: t scales with 1/|d| (cameras.rs:93-97 never normalises)
+    i, h = hit(ob, (0, 0, 0), (0, 0, -4))
+    assert h["t"] == pytest.approx(0.125)
+    # miss and t range (objects.rs:218-222)
+    assert hit(ob, (0, 2, 0), (0, 0, -1))[0] == -1
+    assert hit(ob, (0, 0, 0), (0, 0, -1), tmax=0.4)[0] == -1
+    assert hit(ob, (0, 0, 0), (0, 0, -1), tmin=0.6)[1]["t"] == pytest.approx(1.5)
+
+
+def test_kat2_sphere_uv_table():  # objects.rs:183-185
+    L = oracle()
+    out = (C.c_double * 2)()
+    table = {(1, 0, 0): (0.5, 0.5), (-1, 0, 0): (0.0, 0.5), (0, 1, 0): (0.5, 1.0), (0, -1, 0): (0.5, 0.0),
+             (0, 0, 1): (0.25, 0.5), (0, 0, -1): (0.75, 0.5)}
+    for p, (u, v) in table.items():
+        L.orc_sphere_uv(d3(p), out)
+        assert out[1] == pytest.approx(v, abs=1e-12)
+        if abs(p[1]) != 1:                      # u is arbitrary at the poles
+            assert out[0] % 1.0 == pytest.approx(u % 1.0, abs=1e-12)
+
+
+def test_kat3_rectangle():  # objects.rs:384-411 ; the light of main.rs:136-144
+    ob = OracleBuilder()
+    ob.set_world(ob.list([ob.rectangle(ob.diffuse_light_from_color((4, 4, 4)), 3, 5, 1, 3, -2, rt.RECT_XY)]))
+    i, h = hit(ob, (4, 2, 0), (0, 0, -1))
+    assert i == 0 and h["t"] == pytest.approx(2.0) and (h["u"], h["v"]) == pytest.approx((0.5, 0.5))
+    assert np.allclose(h["n"], (0, 0, 1)) and h["front"]
+    i, h = hit(ob, (4, 2, -4), (0, 0, 1))       # from behind: two-sided, normal flips
+    assert h["t"] == pytest.approx(2.0) and np.allclose(h["n"], (0, 0, -1)) and not h["front"]
+    assert hit(ob, (5.01, 2, 0), (0, 0, -1))[0] == -1 and hit(ob, (5.0, 3.0, 0), (0, 0, -1))[0] == 0   # edges inclusive (:396)
+    for rtype, o, d, n in [(rt.RECT_XZ, (4, 0, 2), (0, -1, 0), (0, 1, 0)), (rt.RECT_YZ, (0, 4, 2), (-1, 0, 0), (1, 0, 0))]:
+        ob2 = OracleBuilder()
+        ob2.set_world(ob2.list([ob2.rectangle(ob2.lambertian((1, 1, 1)), 3, 5, 1, 3, -2, rtype)]))
+        i, h = hit(ob2, o, d)
+        assert i == 0 and h["t"] == pytest.approx(2.0) and np.allclose(h["n"], n)
+
+
+def test_kat4_rotate_y_bbox_and_translate():  # transrot.rs:53-89, 34-38 ; box1 of main.rs:212-218
+    ob = OracleBuilder()
+    box = ob.box((0, 0, 0), (165, 330, 165), ob.lambertian((0.73, 0.73, 0.73)))
+    rot = ob.rotate_y(box, 15.0)
+    tr = ob.translate(rot, (265, 0, 295))
+    out = (C.c_double * 6)()
+    assert oracle().orc_obj_bbox(ob.h, rot, 0.0, 1.0, out) == 0
+    c, s = math.cos(math.radians(15)), math.sin(math.radians(15))
+    want = [0.0, 0.0, -165 * s, 165 * c + 165 * s, 330.0, 165 * c]
+    assert np.allclose(out[:], want, atol=1e-9)
+    assert np.allclose(out[:], [0, 0, -42.705, 202.083, 330, 159.378], atol=1e-3)
+    assert oracle().orc_obj_bbox(ob.h, tr, 0.0, 1.0, out) == 0
+    assert np.allclose(out[:], np.array(want) + [265, 0, 295, 265, 0, 295], atol=1e-9)
+
+
+def test_rotate_y_rebuilds_record_against_object_space_ray():  # transrot.rs:104-115
+    # A Yz rectangle (outward normal +x) rotated by 90 degrees about y faces world -z... hit it from world +z side.
+    ob = OracleBuilder()
+    r = ob.rectangle(ob.lambertian((1, 1, 1)), -1, 1, -1, 1, 0.0, rt.RECT_YZ)
+    ob.set_world(ob.list([ob.rotate_y(r, 90.0)]))
+    i, h = hit(ob, (0, 0, 5), (0, 0, -1))
+    assert i == 0 and h["t"] == pytest.approx(5.0)
+    # inner hit: object ray d' = (cos*dx - sin*dz, ., sin*dx + cos*dz) = (1, 0, ~0); outward (1,0,0) -> back face -> (-1,0,0);
+    # rotated to world: (cos*nx + sin*nz, ., -sin*nx + cos*nz) = (~0, 0, 1); then re-flipped against d' (dot ~ 0-): stays.
+    assert np.allclose(h["n"], (0, 0, 1), atol=1e-12)
+    assert np.allclose(h["p"], (0, 0, 0), atol=1e-12)
+
+
+def test_kat5_camera_frame_cornell():  # cameras.rs:50-65 with configs/cornell.yml
+    cam = rt.make_camera((278, 278, -800), (278, 278, 0), (0, 1, 0), 40.0, 1.0, 0.1, 10.0)
+    f = OracleCamera(cam).fields()
+    h = 2 * math.tan(math.radians(20))
+    assert np.allclose(f["w"], (0, 0, -1)) and np.allclose(f["u"], (-1, 0, 0)) and np.allclose(f["v"], (0, 1, 0))
+    assert h == pytest.approx(0.727940, abs=1e-6)
+    assert np.allclose(f["horizontal"], (-10 * h, 0, 0)) and np.allclose(f["vertical"], (0, 10 * h, 0))
+    assert np.allclose(f["llc"], (278 + 5 * h, 278 - 5 * h, -790)) and f["lens_radius"] == pytest.approx(0.05)
+    assert np.allclose(f["llc"], (281.63970, 274.36030, -790), atol=1e-5)
+
+
+def test_camera_ray_schedule():  # cameras.rs:82-98, main.rs:572-573
+    cam = rt.make_camera((278, 278, -800), (278, 278, 0), (0, 1, 0), 40.0, 1.0, 0.1, 10.0)
+    oc = OracleCamera(cam)
+    f = oc.fields()
+    L = oracle()
+    W, H, px, py, s = 600, 600, 17, 33, 5
+    out = (C.c_double * 7)()
+    L.orc_camera_ray(oc.h, W, H, px, py, s, RENDER_SEED, out)
+    pixel = py * W + px
+    xi = [L.orc_xi(pixel, s, RENDER_SEED, 0, d) for d in range(5)]
+    u = (px + xi[0]) / (W - 1)
+    v = ((H - 1 - py) + xi[1]) / (H - 1)
+    r, phi = math.sqrt(xi[2]), 2 * math.pi * xi[3]
+    off = f["u"] * (0.05 * r * math.cos(phi)) + f["v"] * (0.05 * r * math.sin(phi))
+    assert np.allclose(out[0:3], f["origin"] + off, atol=1e-12)
+    assert np.allclose(out[3:6], f["llc"] + u * f["horizontal"] + v * f["vertical"] - f["origin"] - off, atol=1e-12)
+    assert out[6] == pytest.approx(xi[4])                           # shutter 0..1 -> time = draw
+    cam0 = rt.make_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 40.0, 1.0, 0.0, 1.0, 0.0, 0.0)
+    L.orc_camera_ray(OracleCamera(cam0).h, W, H, px, py, s, RENDER_SEED, out)
+    assert out[6] == 0.0                                            # cameras.rs:86-91: both zero -> time 0
+
+
+def test_kat6_tonemap():  # utils.rs:49-63
+    spp = 16
+    acc = np.array([0.25 * spp, 1.0 * spp, 0.0, 4.0 * spp, -1.0, 0.999 ** 2 * spp], dtype=np.float64)
+    rgb = np.zeros(6, dtype=np.uint8)
+    oracle().orc_tonemap(acc.ctypes.data_as(C.POINTER(C.c_double)), 2, spp, rgb.ctypes.data)
+    assert rgb[0] == 128 and rgb[1] == 255 and rgb[2] == 0 and rgb[3] == 255 and rgb[4] == 0 and rgb[5] in (255, 254)
+
+
+def test_kat7_schlick():  # materials.rs:174-178
+    L = oracle()
+    assert L.orc_reflectance(1.0, 1 / 1.5) == pytest.approx(0.04)
+    assert L.orc_reflectance(0.0, 1.5) == pytest.approx(1.0)
+    assert L.orc_reflectance(0.5, 1.5) == pytest.approx(0.04 + 0.96 * 0.5 ** 5)
+
+
+def test_kat8_refract_reflect():  # utils.rs:79-89
+    L = oracle()
+    out = (C.c_double * 3)()
+    for eta in (1 / 1.5, 1.0, 1.5):
+        L.orc_refract(d3((0, -1, 0)), d3((0, 1, 0)), eta, out)
+        assert np.allclose(out[:], (0, -1, 0))
+    s = math.sqrt(0.5)
+    L.orc_refract(d3((s, -s, 0)), d3((0, 1, 0)), 1 / 1.5, out)         # Snell: sin' = sin/1.5
+    assert out[0] == pytest.approx(s / 1.5) and out[1] == pytest.approx(-math.sqrt(1 - (s / 1.5) ** 2))
+    L.orc_reflect(d3((1, -1, 0)), d3((0, 1, 0)), out)
+    assert np.allclose(out[:], (1, 1, 0))
+
+
+def test_kat9_medium_uses_log10():  # mediums.rs:64
+    # density 0.01: hit_distance = -100 * log10(xi).  A unit-direction ray through a huge sphere collides at exactly that distance.
+    ob = OracleBuilder()
+    bnd = ob.sphere((0, 0, 0), 1e6, ob.dielectric(1.5))
+    med = ob.constant_medium_from_color(bnd, 0.01, (1, 1, 1))
+    ob.set_world(ob.list([med]))
+    L = oracle()
+    for pixel in range(6):
+        xi = L.orc_xi(pixel, 3, RENDER_SEED, 2, 4)                  # medium slot 0 -> dim 4
+        i, h = hit(ob, (0, 0, 0), (1, 0, 0), pixel=pixel, sample=3, bounce=2)
+        want = 0.001 + (-100.0 * math.log10(xi))                    # entry clamped to t_min (mediums.rs:48-50)
+        assert i == 1 and h["t"] == pytest.approx(want, rel=1e-12)
+        assert np.allclose(h["n"], (-1, 0, 0)) and not h["front"]   # mediums.rs:71 normal (1,0,0) flipped against +x ray
+    assert -100.0 * math.log10(0.1) == pytest.approx(100.0) and -100.0 * math.log(0.1) == pytest.approx(230.2585, abs=1e-3)
+    # direction length does not change the collision point (mediums.rs:62-69)
+    xi = L.orc_xi(0, 3, RENDER_SEED, 2, 4)
+    i, h = hit(ob, (0, 0, 0), (4, 0, 0), pixel=0, sample=3, bounce=2)
+    assert h["t"] == pytest.approx(0.001 + (-100.0 * math.log10(xi)) / 4.0, rel=1e-12)
+
+
+def test_medium_misses_when_segment_is_short():  # mediums.rs:51-56, 66-68
+    ob = OracleBuilder()
+    bnd = ob.box((-1, -1, -1), (1, 1, 1), ob.lambertian((1, 1, 1)))
+    med = ob.constant_medium_from_color(bnd, 1e-6, (1, 1, 1))   # mean free path >> box
+    ob.set_world(ob.list([med]))
+    assert all(hit(ob, (-5, 0, 0), (1, 0, 0), pixel=p)[0] == -1 for p in range(20))
+    assert hit(ob, (-5, 0, 0), (1, 0, 0), tmax=3.9)[0] == -1      # interval clipped away entirely
+
+
+def test_kat10_image_height():  # main.rs:515-516
+    L = oracle()
+    assert [L.orc_image_height(w, a) for w, a in ((400, 1.25), (640, 1.25), (600, 1.0), (800, 1.0))] == [320, 512, 600, 800]
+    assert L.orc_image_height(401, 1.25) == 321                   # 320.8 rounds up
+
+
+def test_kat12_mirror_box_returns_black_after_max_depth():  # lib.rs:58-60
+    # A ray bouncing between two parallel perfect mirrors never meets a light: depth runs out -> exactly 0.
+    ob = OracleBuilder()
+    m = ob.metal((1, 1, 1), 0.0)
+    world = ob.list([ob.rectangle(m, -1e3, 1e3, -1e3, 1e3, -1.0, rt.RECT_XY), ob.rectangle(m, -1e3, 1e3, -1e3, 1e3, 1.0, rt.RECT_XY)])
+    ob.set_world(world)
+    cam = rt.make_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 20.0, 1.0, 0.0, 1.0)
+    from helpers import oracle_render
+    acc, _, st = oracle_render(ob, OracleCamera(cam), 4, 4, 2, 7, RENDER_SEED, background=(1, 1, 1), n_threads=1)
+    assert np.all(acc == 0.0) and st["rays"] == 4 * 4 * 2 * 7
+
+
+def test_unit_vector_is_unit_and_uniform():  # utils.rs:13-22 (normalised => on the sphere)
+    out = (C.c_double * 3)()
+    rng = np.random.default_rng(0)
+    pts = []
+    for u1, u2 in rng.random((4000, 2)):
+        oracle().orc_unit_vector(u1, u2, out)
+        pts.append(out[:])
+    pts = np.array(pts)
+    assert np.allclose(np.linalg.norm(pts, axis=1), 1.0, atol=1e-12)
+    assert np.all(np.abs(pts.mean(axis=0)) < 0.05) and np.allclose((pts ** 2).mean(axis=0), 1 / 3, atol=0.03)
+
+
+def test_scatter_rules():  # materials.rs:77-90, 129-145, 181-209, 243-249
+    L = oracle()
+    out = (C.c_double * 13)()
+
+    def one(mat_fn, o=(0, 0, 3), d=(0, 0, -1), pixel=1):
+        ob = OracleBuilder()
+        ob.set_world(ob.list([ob.sphere((0, 0, 0), 1.0, mat_fn(ob))]))
+        st = L.orc_scatter(ob.h, d3(o), d3(d), 0.25, pixel, 2, 1, RENDER_SEED, out)
+        return st, np.array(out[:])
+    xi = [L.orc_xi(1, 2, RENDER_SEED, 1, k) for k in range(3)]
+    z = 1 - 2 * xi[0]; r = math.sqrt(1 - z * z); unit = np.array([r * math.cos(2 * math.pi * xi[1]), r * math.sin(2 * math.pi * xi[1]), z])
+    st, o = one(lambda b: b.lambertian((0.1, 0.2, 0.3)))
+    assert st == 1 and np.allclose(o[3:6], (0.1, 0.2, 0.3)) and np.allclose(o[6:9], (0, 0, 1)) and np.allclose(o[9:12], np.array([0, 0, 1]) + unit)
+    assert o[12] == 0.25 and np.all(o[0:3] == 0)
+    st, o = one(lambda b: b.metal((0.8, 0.6, 0.2), 0.0))
+    assert st == 1 and np.allclose(o[9:12], (0, 0, 1)) and np.allclose(o[3:6], (0.8, 0.6, 0.2))
+    st, o = one(lambda b: b.metal((0.8, 0.6, 0.2), 0.5))
+    assert np.allclose(o[9:12], np.array([0, 0, 1]) + 0.5 * unit)
+    st, o = one(lambda b: b.diffuse_light_from_color((4, 5, 6)))
+    assert st == 0 and np.allclose(o[0:3], (4, 5, 6))
+    st, o = one(lambda b: b.dielectric(1.5))                        # normal incidence: reflect with prob 0.04 else straight through
+    assert st == 1 and np.allclose(o[3:6], 1.0)
+    assert np.allclose(o[9:12], (0, 0, 1) if 0.04 > xi[2] else (0, 0, -1))
+    # total internal reflection from inside at a grazing angle (materials.rs:193)
+    st, o = one(lambda b: b.dielectric(1.5), o=(0, 0.95, 0), d=(1, 0, 0))
+    n_in = -np.array(o[6:9]) / np.linalg.norm(o[6:9])              # hit point on unit sphere = outward normal; flipped inward
+    assert st == 1 and np.allclose(o[9:12], np.array([1, 0, 0]) - 2 * np.dot([1, 0, 0], n_in) * n_in)
+
+
+def test_textures():  # textures.rs:60-69, 87-96, 131-170
+    ob = OracleBuilder()
+    ck = ob.checker_from_solid_colors((1, 0, 0), (0, 1, 0))
+    out = (C.c_double * 3)()
+    L = oracle()
+    L.orc_texture_value(ob.h, ck, 0, 0, d3((0.1, 0.1, 0.1)), out)     # sin(1)^3 > 0 -> even
+    assert out[:] == [1, 0, 0]
+    L.orc_texture_value(ob.h, ck, 0, 0, d3((0.1, 0.1, -0.1)), out)    # one negative factor -> odd
+    assert out[:] == [0, 1, 0]
+    # Perlin with a constant gradient table g: noise(p) = sum_w * g.(p - corner) = g.(frac - hermite)  (interp of a linear field)
+    g = np.array([0.3, -0.2, 0.5])
+    rv = np.tile(g, (256, 1)); perm = np.tile(np.arange(256), 3)
+    nz = ob.noise(1.0, rv, perm)
+    p = np.array([1.25, 2.5, 3.75]); fr = p - np.floor(p); hs = fr * fr * (3 - 2 * fr)
+    noise = float(g @ (fr - hs))
+    turb = abs(sum(0.5 ** i * float(g @ (((p * 2 ** i) % 1.0) - (lambda f: f * f * (3 - 2 * f))((p * 2 ** i) % 1.0))) for i in range(7)))
+    L.orc_texture_value(ob.h, nz, 0, 0, d3(p), out)
+    assert out[0] == pytest.approx(0.5 * (1 + math.sin(1.0 * p[2] + 10 * turb)), abs=1e-12) and out[0] == out[1] == out[2]
+    assert noise == pytest.approx(float(g @ (fr - hs)))
+
+
+def test_moving_sphere_center_and_box():  # objects.rs:285-289, 328-335
+    ob = OracleBuilder()
+    ms = ob.moving_sphere((0, 0, 0), (4, 0, 0), 0.0, 1.0, 1.0, ob.lambertian((1, 1, 1)))
+    ob.set_world(ob.list([ms]))
+    assert hit(ob, (1, 0, 5), (0, 0, -1), time=0.25)[1]["t"] == pytest.approx(4.0)   # centre (1,0,0)
+    assert hit(ob, (1, 0, 5), (0, 0, -1), time=1.0)[0] == -1                          # centre (4,0,0)
+    out = (C.c_double * 6)()
+    oracle().orc_obj_bbox(ob.h, ms, 0.0, 1.0, out)
+    assert out[:] == [-1, -1, -1, 5, 1, 1]
+
+
+def test_bvh_equals_brute_force_on_random_scene():  # bvh.rs:159-187 vs objects.rs:67-78
+    a, b = OracleBuilder(7), OracleBuilder(7)
+    a.set_world(a.canned_scene("Random", 11), True)
+    b.set_world(b.canned_scene("Random", 11), False)
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        o = rng.uniform(-8, 8, 3); o[1] = rng.uniform(0.3, 3)
+        d = rng.normal(size=3)
+        ia, ha = hit(a, o, d, time=0.3)
+        ib, hb = hit(b, o, d, time=0.3)
+        assert ia == ib and (ia < 0 or ha["t"] == hb["t"])

@@ -1,0 +1,58 @@
+"""The N>1 path on CPU: two gloo ranks shard the samples of one image, reduce to rank 0, and the result must be
+the single-process image.  The oracle stands in for the renderer here (test infrastructure); on GPUs the same
+shard/reduce code drives rt_render_device over RCCL (bench.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ray_tracing_amd.distributed import shard_samples
+
+W, H, SPP, DEPTH = 24, 20, 6, 8
+
+
+def test_shard_samples_partitions_the_range():
+    for total in (0, 1, 5, 16, 1000, 100000):
+        for world in (1, 2, 3, 4, 8):
+            parts = [shard_samples(total, r, world) for r in range(world)]
+            assert sum(c for _, c in parts) == total
+            assert parts[0][0] == 0 and all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+    with pytest.raises(ValueError):
+        shard_samples(10, 2, 2)
+
+
+def _oracle_render_into(accum, first, count):
+    import helpers
+    cfg, cam, b, world, ob = helpers.scene_pair("cornell_box.yml")
+    acc, _, _ = helpers.oracle_render(ob, helpers.OracleCamera(cam), W, H, count, DEPTH, helpers.RENDER_SEED, sample_offset=first, n_threads=2)
+    accum += torch.from_numpy(acc.astype(np.float32))
+
+
+def _worker(rank, world_size, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from ray_tracing_amd.distributed import render_sharded
+        accum = render_sharded(_oracle_render_into, H, W, SPP, "cpu")
+        if rank == 0:
+            np.save(out_path, accum.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sample_sharding_equals_single_process(tmp_path):
+    import helpers
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "accum.npy")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    cfg, cam, b, world, ob = helpers.scene_pair("cornell_box.yml")
+    want, _, _ = helpers.oracle_render(ob, helpers.OracleCamera(cam), W, H, SPP, DEPTH, helpers.RENDER_SEED, n_threads=2)
+    assert got.shape == (H, W, 3) and want.sum() > 0
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-5)   # same paths; only the order of the final additions differs
