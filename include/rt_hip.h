@@ -128,6 +128,7 @@ typedef struct RtRenderParams {
     int32_t flags;              /* RT_FLAG_* */
 } RtRenderParams;
 #define RT_FLAG_SUMSQ 1         /* also accumulate per-channel sum of squares (accum_sq must be given) */
+#define RT_FLAG_COUNTERS 2      /* run the instrumented (slower) kernel build and fill RtStats.work */
 
 typedef struct RtStats {
     uint64_t rays;              /* ray segments = executions of src/lib.rs:63 */
@@ -137,6 +138,10 @@ typedef struct RtStats {
     double kernel_ms_extend;    /* summed device time of the closest-hit + scatter kernel (HIP events) */
     uint64_t extend_launches;
     int32_t passes;
+    /* RT_FLAG_COUNTERS only: [0] BVH nodes visited (2 slab tests each), [1] sphere, [2] moving-sphere, [3] rectangle tests,
+     * [4] instance entries, [5] medium tests, [6] misses, [8..12] scatter evaluations per material kind (Lambertian, Metal,
+     * Dielectric, DiffuseLight, Isotropic), [13] Noise-textured, [14] Checker-textured shades. */
+    uint64_t work[16];
 } RtStats;
 
 /* Renders `spp` samples of every pixel and ADDS the per-pixel colour sums (src/main.rs:585-589) to

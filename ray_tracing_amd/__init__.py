@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "librt_hip.so")
 _lib = None
 
 RT_FLAG_SUMSQ = 1
+RT_FLAG_COUNTERS = 2
 RECT_XY, RECT_XZ, RECT_YZ = 0, 1, 2   # RectangleType, src/objects.rs:339-343
 
 
@@ -55,7 +56,7 @@ class RtRenderParams(C.Structure):
 class RtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("rays_per_bounce", C.c_uint64 * 64),
                 ("seconds", C.c_double), ("kernel_ms_extend", C.c_double), ("extend_launches", C.c_uint64),
-                ("passes", C.c_int32)]
+                ("passes", C.c_int32), ("work", C.c_uint64 * 16)]
 
 
 # name -> (restype, argtypes); every symbol include/rt_hip.h declares

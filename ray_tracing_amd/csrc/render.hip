@@ -54,10 +54,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev
     }
 }
 
-// One bounce for every ray of the input queue (lib.rs:63-71, iteratively).
+// One bounce for every ray of the input queue (lib.rs:63-71, iteratively).  STATS = true is the instrumented
+// build that also counts node visits / primitive tests / shades into `work` (16 x u64).
+template <bool STATS>
 __global__ __launch_bounds__(RT_BLOCK) void k_bounce(RtSceneView sc, RtFrameDev fr, int bounce, const uint32_t* n_in_ptr,
                                                      uint32_t* n_out_ptr, const rt_f4* ia, const rt_f4* ib, const rt_f4* ic,
-                                                     rt_f4* oa, rt_f4* ob, rt_f4* oc, rt_f4* contrib) {
+                                                     rt_f4* oa, rt_f4* ob, rt_f4* oc, rt_f4* contrib, unsigned long long* work) {
     __shared__ int s_stack[RT_STACK_DEPTH * RT_BLOCK];
     LdsStack stk; stk.base = s_stack + threadIdx.x;
     const uint32_t n = *n_in_ptr;
@@ -74,8 +76,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(RtSceneView sc, RtFrameDev 
             uint32_t pixel = pid % (uint32_t)fr.n_pixels, sample = (uint32_t)fr.sample_base + pid / (uint32_t)fr.n_pixels;
 
             RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
-            rt_closest_hit(sc, o, d, time, RT_TMIN, src, stk, hit);
+            RtCounters cnt = {0, 0, 0, 0, 0, 0};
+            rt_closest_hit<STATS>(sc, o, d, time, RT_TMIN, src, stk, hit, &cnt);
             if (sc.n_media > 0) rt_media_hits(sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, hit);
+            if (STATS) {
+                atomicAdd(work + 0, (unsigned long long)cnt.nodes); atomicAdd(work + 1, (unsigned long long)cnt.spheres);
+                atomicAdd(work + 2, (unsigned long long)cnt.mspheres); atomicAdd(work + 3, (unsigned long long)cnt.rects);
+                atomicAdd(work + 4, (unsigned long long)cnt.instances); atomicAdd(work + 5, (unsigned long long)sc.n_media);
+                if (hit.code == RT_HIT_NONE) atomicAdd(work + 6, 1ull);
+            }
 
             v3 add = mk3(0, 0, 0);
             if (hit.code == RT_HIT_NONE) {
@@ -87,6 +96,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(RtSceneView sc, RtFrameDev 
                 rt_philox(pixel, sample, (uint32_t)bounce, 0u, fr.key0, fr.key1, rnd);
                 v3 atten, dir, emitted;
                 bool scattered = rt_scatter(sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), rt_u24(rnd[2]), atten, dir, emitted);
+                if (STATS) {
+                    rt_f4 a0 = ld4(sc.materials + 2 * (size_t)sf.mat);
+                    int mtype = f2i(a0.x);
+                    atomicAdd(work + 8 + mtype, 1ull);                                     // shades per material kind
+                    if (mtype != RT_MAT_METAL && mtype != RT_MAT_DIELECTRIC) {            // texture kind behind the material
+                        int tt = f2i(ld4(sc.textures + 2 * (size_t)f2i(a0.y)).x);
+                        if (tt == RT_TEX_NOISE) atomicAdd(work + 13, 1ull); else if (tt == RT_TEX_CHECKER) atomicAdd(work + 14, 1ull);
+                    }
+                }
                 add = beta * emitted;                                                      // lib.rs:64,66
                 if (scattered && bounce < fr.max_depth) {                                 // lib.rs:58-60
                     beta = beta * atten;
@@ -145,7 +163,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(RtSceneView sc, RtCameraDe
     v3 o, d; float time;
     rt_camera_ray(cam, fr, pixel, sample, o, d, time);
     RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
-    rt_closest_hit(sc, o, d, time, RT_TMIN, RT_HIT_NONE, stk, hit);
+    rt_closest_hit<false>(sc, o, d, time, RT_TMIN, RT_HIT_NONE, stk, hit, nullptr);
     if (sc.n_media > 0) rt_media_hits(sc, o, d, time, RT_TMIN, pixel, sample, 1u, fr.key0, fr.key1, hit);
     RtSurface sf; sf.id = -1; sf.n = mk3(0, 0, 0); sf.front = false; sf.u = sf.v = 0.0f;
     if (hit.code != RT_HIT_NONE) rt_surface(sc, o, d, time, hit, true, sf);
@@ -166,7 +184,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_scatter_rays(RtSceneView sc, const
     v3 o = mk3(r[0], r[1], r[2]), d = mk3(r[3], r[4], r[5]); float time = r[6];
     uint32_t pixel = pixel0 + (uint32_t)i;
     RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
-    rt_closest_hit(sc, o, d, time, RT_TMIN, RT_HIT_NONE, stk, hit);
+    rt_closest_hit<false>(sc, o, d, time, RT_TMIN, RT_HIT_NONE, stk, hit, nullptr);
     if (sc.n_media > 0) rt_media_hits(sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, key0, key1, hit);
     float* w = out + 14 * (size_t)i;
     for (int k = 0; k < 14; ++k) w[k] = 0.0f;
@@ -194,6 +212,7 @@ struct RtScene {
     size_t ws_paths = 0;
     rt_f4 *qa[2] = {nullptr, nullptr}, *qb[2] = {nullptr, nullptr}, *qc[2] = {nullptr, nullptr}, *contrib = nullptr;
     uint32_t* counts = nullptr;
+    unsigned long long* work = nullptr;   // 16 work counters of the instrumented kernel
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
@@ -218,6 +237,7 @@ static void free_workspace(RtScene* s) {
 }
 static int ensure_workspace(RtScene* s, size_t n_paths) {
     if (!s->counts) { HIP_TRY(hipMalloc((void**)&s->counts, RT_MAX_BOUNCE_COUNTS * sizeof(uint32_t))); }
+    if (!s->work) { HIP_TRY(hipMalloc((void**)&s->work, 16 * sizeof(unsigned long long))); }
     if (!s->ev0) { HIP_TRY(hipEventCreate(&s->ev0)); HIP_TRY(hipEventCreate(&s->ev1)); }
     if (s->ws_paths >= n_paths) return RT_OK;
     free_workspace(s);
@@ -316,6 +336,7 @@ void rt_scene_destroy(RtScene* s) {
     for (void* p : s->allocs) (void)hipFree(p);
     free_workspace(s);
     if (s->counts) (void)hipFree(s->counts);
+    if (s->work) (void)hipFree(s->work);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     delete s;
@@ -364,6 +385,8 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     std::vector<uint32_t> h_counts(RT_MAX_BOUNCE_COUNTS);
     const int grid_cap = std::max(1, s->n_cu) * 32;
     float* sq = (p->flags & RT_FLAG_SUMSQ) ? d_accum_sq : nullptr;
+    const bool instrumented = (p->flags & RT_FLAG_COUNTERS) != 0;
+    if (instrumented) HIP_TRY(hipMemsetAsync(s->work, 0, 16 * sizeof(unsigned long long), st));
 
     for (int done = 0; done < p->spp;) {
         int chunk = std::min(chunk_max, p->spp - done);
@@ -377,8 +400,12 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         HIP_TRY(hipEventRecord(s->ev0, st));
         for (int b = 1; b <= p->max_depth; ++b) {
             int in = (b - 1) & 1, outq = b & 1;
-            hipLaunchKernelGGL(k_bounce, dim3(grid), dim3(RT_BLOCK), 0, st, s->view, fr, b, s->counts + b, s->counts + b + 1,
-                               s->qa[in], s->qb[in], s->qc[in], s->qa[outq], s->qb[outq], s->qc[outq], s->contrib);
+            if (instrumented)
+                hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(RT_BLOCK), 0, st, s->view, fr, b, s->counts + b, s->counts + b + 1,
+                                   s->qa[in], s->qb[in], s->qc[in], s->qa[outq], s->qb[outq], s->qc[outq], s->contrib, s->work);
+            else
+                hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(RT_BLOCK), 0, st, s->view, fr, b, s->counts + b, s->counts + b + 1,
+                                   s->qa[in], s->qb[in], s->qc[in], s->qa[outq], s->qb[outq], s->qc[outq], s->contrib, s->work);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(s->ev1, st));
@@ -395,6 +422,11 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
             if (b <= 64) local.rays_per_bounce[b - 1] += h_counts[b];
         }
         done += chunk;
+    }
+    if (instrumented) {
+        unsigned long long w[16];
+        HIP_TRY(hipMemcpy(w, s->work, sizeof(w), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 16; ++i) local.work[i] = w[i];
     }
     local.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     if (stats) *stats = local;

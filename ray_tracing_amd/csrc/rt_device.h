@@ -224,6 +224,9 @@ RT_HD v3 rt_to_object_dir(rt_f4 i0, v3 d) {
 
 struct RtHit { float t; uint32_t code; int32_t inst; };
 
+// Work counters of an instrumented build (STATS = true); the normal kernels compile them away.
+struct RtCounters { uint32_t nodes, spheres, mspheres, rects, instances, media; };
+
 // ------------------------------------------------------------------ closest surface hit
 // Stack-based traversal of the two-level BVH; equivalent to bvh.rs:159-187 + objects.rs:67-78
 // (closest hit is independent of tree shape and visiting order, ties aside).  `src` is the hit
@@ -231,8 +234,9 @@ struct RtHit { float t; uint32_t code; int32_t inst; };
 // planar primitive can never be re-hit from itself and a sphere only through its far root, which
 // replaces the reference's reliance on f64 round-off staying below t_min.
 // On entry hit.t = tmax, hit.code = RT_HIT_NONE.  Stack: set(i, v) / get(i) on an int array.
-template <class Stack>
-RT_HD void rt_closest_hit(const RtSceneView& sc, v3 wo, v3 wd, float time, float tmin, uint32_t src, Stack& stk, RtHit& hit) {
+template <bool STATS, class Stack>
+RT_HD void rt_closest_hit(const RtSceneView& sc, v3 wo, v3 wd, float time, float tmin, uint32_t src, Stack& stk, RtHit& hit,
+                          RtCounters* wc) {
     if (sc.root < 0) return;
     v3 o = wo, d = wd;
     v3 inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
@@ -247,6 +251,7 @@ RT_HD void rt_closest_hit(const RtSceneView& sc, v3 wo, v3 wd, float time, float
             }
             const rt_f4* n = sc.nodes + 4 * (size_t)cur;
             rt_f4 q0 = ld4(n), q1 = ld4(n + 1), q2 = ld4(n + 2), q3 = ld4(n + 3);
+            if (STATS) wc->nodes++;
             float tl = rt_slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tmin, hit.t);
             float tr = rt_slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tmin, hit.t);
             int32_t cl = f2i(q3.x), cr = f2i(q3.y);
@@ -266,6 +271,7 @@ RT_HD void rt_closest_hit(const RtSceneView& sc, v3 wo, v3 wd, float time, float
             rt_f4 i0 = ld4(sc.instances + 2 * (size_t)ii), i1 = ld4(sc.instances + 2 * (size_t)ii + 1);
             if (sp < RT_STACK_DEPTH) stk.set(sp++, RT_SENTINEL);
             inst = ii;
+            if (STATS) wc->instances++;
             o = rt_to_object_point(i0, i1, wo); d = rt_to_object_dir(i0, wd);
             inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
             cur = f2i(i1.y);
@@ -278,7 +284,9 @@ RT_HD void rt_closest_hit(const RtSceneView& sc, v3 wo, v3 wd, float time, float
             if (kind == RT_KIND_SPHERE) {
                 rt_f4 s = ld4(sc.spheres + idx);
                 t = rt_hit_sphere(mk3(s.x, s.y, s.z), s.w, o, d, tmin, hit.t, code == src);
+                if (STATS) wc->spheres++;
             } else if (kind == RT_KIND_RECT) {
+                if (STATS) wc->rects++;
                 if (code == src) continue;
                 rt_f4 r0 = ld4(sc.rects + 2 * (size_t)idx), r1 = ld4(sc.rects + 2 * (size_t)idx + 1);
                 t = rt_hit_rect(r0, r1.x, f2i(r1.y), o, d, tmin, hit.t);
@@ -286,6 +294,7 @@ RT_HD void rt_closest_hit(const RtSceneView& sc, v3 wo, v3 wd, float time, float
                 const rt_f4* m = sc.mspheres + 3 * (size_t)idx;
                 rt_f4 m0 = ld4(m), m1 = ld4(m + 1), m2 = ld4(m + 2);
                 t = rt_hit_sphere(rt_msphere_center(m0, m1, m2, time), m0.w, o, d, tmin, hit.t, code == src);
+                if (STATS) wc->mspheres++;
             }
             if (t < hit.t) { hit.t = t; hit.code = code; hit.inst = inst; }  // false for NaN
         }

@@ -46,7 +46,7 @@ void emul_trace_primary(const RtSceneView* sc, const RtCamera* cam, const RtRend
         rt_camera_ray(cd, fr, pixel, (uint32_t)sample, o, d, time);
         ArrStack stk;
         RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
-        rt_closest_hit(*sc, o, d, time, RT_TMIN, RT_HIT_NONE, stk, hit);
+        rt_closest_hit<false>(*sc, o, d, time, RT_TMIN, RT_HIT_NONE, stk, hit, nullptr);
         if (sc->n_media > 0) rt_media_hits(*sc, o, d, time, RT_TMIN, pixel, (uint32_t)sample, 1u, fr.key0, fr.key1, hit);
         RtSurface sf; sf.id = -1; sf.n = mk3(0, 0, 0); sf.front = false; sf.u = sf.v = 0;
         if (hit.code != RT_HIT_NONE) rt_surface(*sc, o, d, time, hit, true, sf);
@@ -76,7 +76,7 @@ void emul_render(const RtSceneView* sc, const RtCamera* cam, const RtRenderParam
                     rays[(size_t)tid]++;
                     ArrStack stk;
                     RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
-                    rt_closest_hit(*sc, o, d, time, RT_TMIN, src, stk, hit);
+                    rt_closest_hit<false>(*sc, o, d, time, RT_TMIN, src, stk, hit, nullptr);
                     if (sc->n_media > 0) rt_media_hits(*sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, hit);
                     if (hit.code == RT_HIT_NONE) { L = L + beta * mk3(fr.background[0], fr.background[1], fr.background[2]); break; }
                     RtSurface sf; rt_surface(*sc, o, d, time, hit, false, sf);
@@ -109,7 +109,7 @@ void emul_scatter_rays(const RtSceneView* sc, const float* rays, int32_t n, uint
         uint32_t pixel = pixel0 + (uint32_t)i, key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32);
         ArrStack stk;
         RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
-        rt_closest_hit(*sc, o, d, time, RT_TMIN, RT_HIT_NONE, stk, hit);
+        rt_closest_hit<false>(*sc, o, d, time, RT_TMIN, RT_HIT_NONE, stk, hit, nullptr);
         if (sc->n_media > 0) rt_media_hits(*sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, key0, key1, hit);
         float* w = out + 14 * (size_t)i;
         for (int k = 0; k < 14; ++k) w[k] = 0.0f;
