@@ -129,6 +129,7 @@ typedef struct RtRenderParams {
 } RtRenderParams;
 #define RT_FLAG_SUMSQ 1         /* also accumulate per-channel sum of squares (accum_sq must be given) */
 #define RT_FLAG_COUNTERS 2      /* run the instrumented (slower) kernel build and fill RtStats.work */
+#define RT_FLAG_ABLATE_SHIFT 8  /* bits 8..10: timing-only ablation builds (WRONG images): 1 no media, 2 no traversal, 4 no scatter */
 
 typedef struct RtStats {
     uint64_t rays;              /* ray segments = executions of src/lib.rs:63 */

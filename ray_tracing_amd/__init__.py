@@ -111,6 +111,15 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing: run `python -m ray_tracing_amd.build` (needs hipcc); "
                               "there is no CPU fallback for the render path" % LIB_PATH)
+        # PyTorch-ROCm bundles its own HIP runtime (same soname as the system one).  Two runtimes in one process
+        # leave the second user without a GPU, so when torch is installed it is imported first and the library
+        # binds to the runtime torch brought in; device pointers are then shared between the two.
+        import sys
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in API.items():
             fn = getattr(L, name)

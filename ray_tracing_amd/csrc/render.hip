@@ -8,8 +8,12 @@
 //                   radiance to their private slot of the contribution buffer
 //   k_accumulate  : per pixel, sums the pass's contributions in sample order into the caller's
 //                   accumulation buffer (deterministic; no float atomics anywhere)
-// Queue sizes live in device memory (counts[b] = rays entering bounce b), so a pass runs without a
-// host round trip; the counts double as the ray-segment statistics.
+// A ray queue is RT_SHARDS regions of `cap` slots, each with its own counter: a single append counter saturates
+// at ~88 M returning atomics/s on this GPU (= 5.6 Grays/s at one atomic per 64-lane wave), 16 counters do not.
+// Block (x, y) of the bounce grid reads region y and appends to region (x + y) % RT_SHARDS; with gridDim.x a
+// multiple of RT_SHARDS no region can receive more than n/RT_SHARDS + 256 * (RT_SHARDS + 1) rays.
+// Queue sizes live in device memory (counts[b][s] = rays of region s entering bounce b), so a pass runs
+// without a host round trip; the counts double as the ray-segment statistics.
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
@@ -20,7 +24,9 @@
 #include "rt_device.h"
 
 #define RT_BLOCK 256
-#define RT_MAX_BOUNCE_COUNTS 1024
+#define RT_SHARDS 16
+#define RT_COUNT_STRIDE 32   /* uint32 words between two region counters: one 128-B line each, so the atomics spread over L2 channels */
+#define RT_MAX_BOUNCES 1024
 
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
@@ -37,9 +43,16 @@ struct LdsStack {  // one column of the block's LDS stack: entry i of thread t l
     __host__ __device__ int get(int i) const { return base[i * RT_BLOCK]; }
 };
 
-__global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev fr, uint32_t n_paths, uint32_t* counts,
+__global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev fr, uint32_t n_paths, uint32_t cap, uint32_t* counts1,
                                                      rt_f4* qa, rt_f4* qb, rt_f4* qc) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) counts[1] = n_paths;
+    // Chunks of 256 consecutive path ids are dealt round-robin to the regions.
+    if (blockIdx.x == 0 && threadIdx.x < RT_SHARDS) {
+        uint32_t n_chunks = (n_paths + RT_BLOCK - 1) / RT_BLOCK, sh = threadIdx.x;
+        uint32_t mine = n_chunks / RT_SHARDS + (sh < n_chunks % RT_SHARDS ? 1u : 0u);
+        uint32_t cnt = mine * RT_BLOCK;
+        if (n_chunks > 0 && (n_chunks - 1) % RT_SHARDS == sh) cnt -= n_chunks * RT_BLOCK - n_paths;  // the last, partial chunk
+        counts1[sh * RT_COUNT_STRIDE] = cnt;
+    }
     for (uint32_t pid = blockIdx.x * RT_BLOCK + threadIdx.x; pid < n_paths; pid += gridDim.x * RT_BLOCK) {
         uint32_t pixel = pid % (uint32_t)fr.n_pixels, s = pid / (uint32_t)fr.n_pixels;
         v3 o, d; float time;
@@ -48,21 +61,29 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev
         a.x = o.x; a.y = o.y; a.z = o.z; a.w = time;
         b.x = d.x; b.y = d.y; b.z = d.z; b.w = i2f((int)RT_HIT_NONE);
         c.x = 1.0f; c.y = 1.0f; c.z = 1.0f; c.w = i2f((int)pid);
-        *reinterpret_cast<float4*>(qa + pid) = make_float4(a.x, a.y, a.z, a.w);
-        *reinterpret_cast<float4*>(qb + pid) = make_float4(b.x, b.y, b.z, b.w);
-        *reinterpret_cast<float4*>(qc + pid) = make_float4(c.x, c.y, c.z, c.w);
+        uint32_t chunk = pid / RT_BLOCK;
+        size_t slot = (size_t)(chunk % RT_SHARDS) * cap + (size_t)(chunk / RT_SHARDS) * RT_BLOCK + pid % RT_BLOCK;
+        *reinterpret_cast<float4*>(qa + slot) = make_float4(a.x, a.y, a.z, a.w);
+        *reinterpret_cast<float4*>(qb + slot) = make_float4(b.x, b.y, b.z, b.w);
+        *reinterpret_cast<float4*>(qc + slot) = make_float4(c.x, c.y, c.z, c.w);
     }
 }
 
 // One bounce for every ray of the input queue (lib.rs:63-71, iteratively).  STATS = true is the instrumented
 // build that also counts node visits / primitive tests / shades into `work` (16 x u64).
-template <bool STATS>
-__global__ __launch_bounds__(RT_BLOCK) void k_bounce(RtSceneView sc, RtFrameDev fr, int bounce, const uint32_t* n_in_ptr,
-                                                     uint32_t* n_out_ptr, const rt_f4* ia, const rt_f4* ib, const rt_f4* ic,
+// ABL is a timing-only ablation mask (results are wrong when non-zero): 1 = no media, 2 = no traversal
+// (every ray "hits" primitive 0 of the first non-empty kind at t = 1), 4 = no scatter (fixed attenuation, bounce along the normal).
+template <bool STATS, int ABL>
+__global__ __launch_bounds__(RT_BLOCK) void k_bounce(RtSceneView sc, RtFrameDev fr, int bounce, uint32_t cap, const uint32_t* counts_in,
+                                                     uint32_t* counts_out, const rt_f4* ia, const rt_f4* ib, const rt_f4* ic,
                                                      rt_f4* oa, rt_f4* ob, rt_f4* oc, rt_f4* contrib, unsigned long long* work) {
     __shared__ int s_stack[RT_STACK_DEPTH * RT_BLOCK];
     LdsStack stk; stk.base = s_stack + threadIdx.x;
-    const uint32_t n = *n_in_ptr;
+    const uint32_t n = counts_in[blockIdx.y * RT_COUNT_STRIDE];
+    const uint32_t out_shard = (blockIdx.x + blockIdx.y) % RT_SHARDS;
+    uint32_t* n_out_ptr = counts_out + out_shard * RT_COUNT_STRIDE;
+    ia += (size_t)blockIdx.y * cap; ib += (size_t)blockIdx.y * cap; ic += (size_t)blockIdx.y * cap;
+    oa += (size_t)out_shard * cap; ob += (size_t)out_shard * cap; oc += (size_t)out_shard * cap;
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
         uint32_t i = base + threadIdx.x;
         bool alive = false;
@@ -77,8 +98,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(RtSceneView sc, RtFrameDev 
 
             RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
             RtCounters cnt = {0, 0, 0, 0, 0, 0};
-            rt_closest_hit<STATS>(sc, o, d, time, RT_TMIN, src, stk, hit, &cnt);
-            if (sc.n_media > 0) rt_media_hits(sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, hit);
+            if (ABL & 2) { hit.t = 1.0f; hit.code = RT_HIT_CODE(sc.n_rects > 0 ? RT_KIND_RECT : RT_KIND_SPHERE, pid % 5u); }
+            else rt_closest_hit<STATS>(sc, o, d, time, RT_TMIN, src, stk, hit, &cnt);
+            if (!(ABL & 1) && sc.n_media > 0) rt_media_hits(sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, hit);
             if (STATS) {
                 atomicAdd(work + 0, (unsigned long long)cnt.nodes); atomicAdd(work + 1, (unsigned long long)cnt.spheres);
                 atomicAdd(work + 2, (unsigned long long)cnt.mspheres); atomicAdd(work + 3, (unsigned long long)cnt.rects);
@@ -95,7 +117,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(RtSceneView sc, RtFrameDev 
                 uint32_t rnd[4];
                 rt_philox(pixel, sample, (uint32_t)bounce, 0u, fr.key0, fr.key1, rnd);
                 v3 atten, dir, emitted;
-                bool scattered = rt_scatter(sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), rt_u24(rnd[2]), atten, dir, emitted);
+                bool scattered;
+                if (ABL & 4) { atten = mk3(0.8f, 0.8f, 0.8f); dir = sf.n + mk3(rt_u24(rnd[0]), rt_u24(rnd[1]), rt_u24(rnd[2])); emitted = mk3(0, 0, 0); scattered = rnd[3] > 0x30000000u; }
+                else scattered = rt_scatter(sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), rt_u24(rnd[2]), atten, dir, emitted);
                 if (STATS) {
                     rt_f4 a0 = ld4(sc.materials + 2 * (size_t)sf.mat);
                     int mtype = f2i(a0.x);
@@ -129,7 +153,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(RtSceneView sc, RtFrameDev 
             uint32_t slot0 = 0;
             if (alive && rank == 0) slot0 = atomicAdd(n_out_ptr, (uint32_t)__popcll(mask));
             slot0 = __shfl(slot0, __ffsll((long long)mask) - 1);
-            if (alive) {
+            if (alive && slot0 + rank < cap) {  // the capacity bound holds by construction; the test only guards memory
                 uint32_t slot = slot0 + rank;
                 *reinterpret_cast<float4*>(oa + slot) = make_float4(na.x, na.y, na.z, na.w);
                 *reinterpret_cast<float4*>(ob + slot) = make_float4(nb.x, nb.y, nb.z, nb.w);
@@ -209,7 +233,7 @@ struct RtScene {
     std::vector<void*> allocs;     // scene arrays
     uint64_t device_bytes = 0;
     // render workspace (grow-only)
-    size_t ws_paths = 0;
+    size_t ws_paths = 0, ws_cap = 0;   // paths the workspace was sized for; slots per queue region
     rt_f4 *qa[2] = {nullptr, nullptr}, *qb[2] = {nullptr, nullptr}, *qc[2] = {nullptr, nullptr}, *contrib = nullptr;
     uint32_t* counts = nullptr;
     unsigned long long* work = nullptr;   // 16 work counters of the instrumented kernel
@@ -233,21 +257,23 @@ static int upload(RtScene* s, const std::vector<T>& v, const T** out) {
 static void free_workspace(RtScene* s) {
     for (int i = 0; i < 2; ++i) { if (s->qa[i]) (void)hipFree(s->qa[i]); if (s->qb[i]) (void)hipFree(s->qb[i]); if (s->qc[i]) (void)hipFree(s->qc[i]); s->qa[i] = s->qb[i] = s->qc[i] = nullptr; }
     if (s->contrib) (void)hipFree(s->contrib);
-    s->contrib = nullptr; s->ws_paths = 0;
+    s->contrib = nullptr; s->ws_paths = 0; s->ws_cap = 0;
 }
 static int ensure_workspace(RtScene* s, size_t n_paths) {
-    if (!s->counts) { HIP_TRY(hipMalloc((void**)&s->counts, RT_MAX_BOUNCE_COUNTS * sizeof(uint32_t))); }
+    if (!s->counts) { HIP_TRY(hipMalloc((void**)&s->counts, (size_t)(RT_MAX_BOUNCES + 2) * RT_SHARDS * RT_COUNT_STRIDE * sizeof(uint32_t))); }
     if (!s->work) { HIP_TRY(hipMalloc((void**)&s->work, 16 * sizeof(unsigned long long))); }
     if (!s->ev0) { HIP_TRY(hipEventCreate(&s->ev0)); HIP_TRY(hipEventCreate(&s->ev1)); }
     if (s->ws_paths >= n_paths) return RT_OK;
     free_workspace(s);
+    size_t cap = (n_paths + RT_SHARDS - 1) / RT_SHARDS + (size_t)RT_BLOCK * (RT_SHARDS + 2);
+    cap = (cap + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK;
     for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipMalloc((void**)&s->qa[i], n_paths * sizeof(rt_f4)));
-        HIP_TRY(hipMalloc((void**)&s->qb[i], n_paths * sizeof(rt_f4)));
-        HIP_TRY(hipMalloc((void**)&s->qc[i], n_paths * sizeof(rt_f4)));
+        HIP_TRY(hipMalloc((void**)&s->qa[i], cap * RT_SHARDS * sizeof(rt_f4)));
+        HIP_TRY(hipMalloc((void**)&s->qb[i], cap * RT_SHARDS * sizeof(rt_f4)));
+        HIP_TRY(hipMalloc((void**)&s->qc[i], cap * RT_SHARDS * sizeof(rt_f4)));
     }
     HIP_TRY(hipMalloc((void**)&s->contrib, n_paths * sizeof(rt_f4)));
-    s->ws_paths = n_paths;
+    s->ws_paths = n_paths; s->ws_cap = cap;
     return RT_OK;
 }
 
@@ -255,7 +281,7 @@ static int check_common(const RtScene* s, const RtCamera* cam, const RtRenderPar
     if (!s || !cam || !p) return rt_set_error(RT_ERR_INVALID, "null argument");
     if (p->width < 2 || p->height < 2) return rt_set_error(RT_ERR_INVALID, "width and height must be >= 2 (main.rs:572-573 divides by W-1, H-1)");
     if ((uint64_t)p->width * (uint64_t)p->height > 0x7FFFFFFFull / 4) return rt_set_error(RT_ERR_INVALID, "image too large");
-    if (p->max_depth < 0 || p->max_depth > RT_MAX_BOUNCE_COUNTS - 2) return rt_set_error(RT_ERR_INVALID, "max_depth out of range");
+    if (p->max_depth < 0 || p->max_depth > RT_MAX_BOUNCES) return rt_set_error(RT_ERR_INVALID, "max_depth out of range");
     if (s->flat.max_stack > RT_STACK_DEPTH) return rt_set_error(RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
     return RT_OK;
 }
@@ -382,8 +408,10 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
 
     RtStats local; std::memset(&local, 0, sizeof(local));
     local.paths = (uint64_t)n_pixels * (uint64_t)p->spp;
-    std::vector<uint32_t> h_counts(RT_MAX_BOUNCE_COUNTS);
+    std::vector<uint32_t> h_counts((size_t)(p->max_depth + 2) * RT_SHARDS * RT_COUNT_STRIDE);
+    const size_t counts_bytes = h_counts.size() * sizeof(uint32_t);
     const int grid_cap = std::max(1, s->n_cu) * 32;
+    const uint32_t cap = (uint32_t)s->ws_cap;
     float* sq = (p->flags & RT_FLAG_SUMSQ) ? d_accum_sq : nullptr;
     const bool instrumented = (p->flags & RT_FLAG_COUNTERS) != 0;
     if (instrumented) HIP_TRY(hipMemsetAsync(s->work, 0, 16 * sizeof(unsigned long long), st));
@@ -392,34 +420,49 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         int chunk = std::min(chunk_max, p->spp - done);
         uint32_t n_paths = (uint32_t)((size_t)chunk * n_pixels);
         fr.spp_chunk = chunk; fr.sample_base = p->sample_offset + done;
-        HIP_TRY(hipMemsetAsync(s->counts, 0, (size_t)(p->max_depth + 2) * sizeof(uint32_t), st));
+        HIP_TRY(hipMemsetAsync(s->counts, 0, counts_bytes, st));
         HIP_TRY(hipMemsetAsync(s->contrib, 0, (size_t)n_paths * sizeof(rt_f4), st));
         int grid = (int)std::min<size_t>(((size_t)n_paths + RT_BLOCK - 1) / RT_BLOCK, (size_t)grid_cap);
-        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, cd, fr, n_paths, s->counts, s->qa[0], s->qb[0], s->qc[0]);
+        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, cd, fr, n_paths, cap, s->counts + RT_SHARDS * RT_COUNT_STRIDE, s->qa[0], s->qb[0], s->qc[0]);
+        // bounce grid: x = blocks per region (a multiple of RT_SHARDS, see the capacity argument above), y = region
+        int gx = (int)std::min<size_t>(((size_t)n_paths / RT_SHARDS + RT_BLOCK - 1) / RT_BLOCK + 1, (size_t)grid_cap / RT_SHARDS);
+        gx = std::max(RT_SHARDS, (gx + RT_SHARDS - 1) / RT_SHARDS * RT_SHARDS);
+        dim3 bgrid((unsigned)gx, RT_SHARDS);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(s->ev0, st));
         for (int b = 1; b <= p->max_depth; ++b) {
             int in = (b - 1) & 1, outq = b & 1;
-            if (instrumented)
-                hipLaunchKernelGGL(k_bounce<true>, dim3(grid), dim3(RT_BLOCK), 0, st, s->view, fr, b, s->counts + b, s->counts + b + 1,
-                                   s->qa[in], s->qb[in], s->qc[in], s->qa[outq], s->qb[outq], s->qc[outq], s->contrib, s->work);
-            else
-                hipLaunchKernelGGL(k_bounce<false>, dim3(grid), dim3(RT_BLOCK), 0, st, s->view, fr, b, s->counts + b, s->counts + b + 1,
-                                   s->qa[in], s->qb[in], s->qc[in], s->qa[outq], s->qb[outq], s->qc[outq], s->contrib, s->work);
+#define RT_LAUNCH_BOUNCE(STATS_, ABL_)                                                                                         \
+    hipLaunchKernelGGL((k_bounce<STATS_, ABL_>), bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, s->counts + (size_t)b * RT_SHARDS * RT_COUNT_STRIDE, \
+                       s->counts + (size_t)(b + 1) * RT_SHARDS * RT_COUNT_STRIDE,                                                                     \
+                       s->qa[in], s->qb[in], s->qc[in], s->qa[outq], s->qb[outq], s->qc[outq], s->contrib, s->work)
+            switch (instrumented ? -1 : ((p->flags >> 8) & 7)) {
+                case -1: RT_LAUNCH_BOUNCE(true, 0); break;
+                case 1: RT_LAUNCH_BOUNCE(false, 1); break;
+                case 2: RT_LAUNCH_BOUNCE(false, 2); break;
+                case 3: RT_LAUNCH_BOUNCE(false, 3); break;
+                case 4: RT_LAUNCH_BOUNCE(false, 4); break;
+                case 5: RT_LAUNCH_BOUNCE(false, 5); break;
+                case 7: RT_LAUNCH_BOUNCE(false, 7); break;
+                default: RT_LAUNCH_BOUNCE(false, 0); break;
+            }
+#undef RT_LAUNCH_BOUNCE
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(s->ev1, st));
         int agrid = (int)((n_pixels + RT_BLOCK - 1) / RT_BLOCK);
         hipLaunchKernelGGL(k_accumulate, dim3(agrid), dim3(RT_BLOCK), 0, st, s->contrib, (int)n_pixels, chunk, d_accum, sq);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h_counts.data(), s->counts, (size_t)(p->max_depth + 2) * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_counts.data(), s->counts, counts_bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
         local.kernel_ms_extend += ms; local.extend_launches += (uint64_t)p->max_depth; local.passes++;
         for (int b = 1; b <= p->max_depth; ++b) {
-            local.rays += h_counts[b];
-            if (b <= 64) local.rays_per_bounce[b - 1] += h_counts[b];
+            uint64_t nb = 0;
+            for (int sh = 0; sh < RT_SHARDS; ++sh) nb += h_counts[((size_t)b * RT_SHARDS + sh) * RT_COUNT_STRIDE];
+            local.rays += nb;
+            if (b <= 64) local.rays_per_bounce[b - 1] += nb;
         }
         done += chunk;
     }

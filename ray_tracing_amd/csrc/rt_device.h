@@ -241,14 +241,11 @@ RT_HD void rt_closest_hit(const RtSceneView& sc, v3 wo, v3 wd, float time, float
     v3 o = wo, d = wd;
     v3 inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
     int32_t inst = -1, sp = 0, cur = sc.root;
+    // "while-while" organisation: every lane first descends inner nodes until it holds a leaf, then the wave
+    // works on leaves together.  On a 64-wide wave this keeps the box-test code and the primitive code from
+    // being issued in turn for every step of every lane.
     for (;;) {
-        if (cur >= 0) {
-            if (cur >= RT_SENTINEL) {
-                if (cur == RT_EMPTY_STACK) break;
-                o = wo; d = wd; inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z)); inst = -1;  // left the instance
-                cur = sp > 0 ? stk.get(--sp) : RT_EMPTY_STACK;
-                continue;
-            }
+        while ((uint32_t)cur < (uint32_t)RT_SENTINEL) {  // inner node
             const rt_f4* n = sc.nodes + 4 * (size_t)cur;
             rt_f4 q0 = ld4(n), q1 = ld4(n + 1), q2 = ld4(n + 2), q3 = ld4(n + 3);
             if (STATS) wc->nodes++;
@@ -263,42 +260,53 @@ RT_HD void rt_closest_hit(const RtSceneView& sc, v3 wo, v3 wd, float time, float
             } else if (hl) cur = cl;
             else if (hr) cur = cr;
             else cur = sp > 0 ? stk.get(--sp) : RT_EMPTY_STACK;
+        }
+        if (cur >= 0) {
+            if (cur == RT_EMPTY_STACK) break;
+            o = wo; d = wd; inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z)); inst = -1;  // sentinel: left the instance
+            cur = sp > 0 ? stk.get(--sp) : RT_EMPTY_STACK;
             continue;
         }
-        uint32_t x = ~(uint32_t)cur;
-        if (x & RT_LEAF_INSTANCE_BIT) {
-            int32_t ii = (int32_t)(x & 0x3FFFFFFFu);
-            rt_f4 i0 = ld4(sc.instances + 2 * (size_t)ii), i1 = ld4(sc.instances + 2 * (size_t)ii + 1);
-            if (sp < RT_STACK_DEPTH) stk.set(sp++, RT_SENTINEL);
-            inst = ii;
-            if (STATS) wc->instances++;
-            o = rt_to_object_point(i0, i1, wo); d = rt_to_object_dir(i0, wd);
-            inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
-            cur = f2i(i1.y);
-            continue;
-        }
-        uint32_t kind = (x >> 28) & 3u, cnt = ((x >> 26) & 3u) + 1u, first = x & 0x03FFFFFFu;
-        for (uint32_t k = 0; k < cnt; ++k) {
-            uint32_t idx = first + k, code = RT_HIT_CODE(kind, idx);
-            float t;
-            if (kind == RT_KIND_SPHERE) {
-                rt_f4 s = ld4(sc.spheres + idx);
-                t = rt_hit_sphere(mk3(s.x, s.y, s.z), s.w, o, d, tmin, hit.t, code == src);
-                if (STATS) wc->spheres++;
-            } else if (kind == RT_KIND_RECT) {
-                if (STATS) wc->rects++;
-                if (code == src) continue;
-                rt_f4 r0 = ld4(sc.rects + 2 * (size_t)idx), r1 = ld4(sc.rects + 2 * (size_t)idx + 1);
-                t = rt_hit_rect(r0, r1.x, f2i(r1.y), o, d, tmin, hit.t);
-            } else {
-                const rt_f4* m = sc.mspheres + 3 * (size_t)idx;
-                rt_f4 m0 = ld4(m), m1 = ld4(m + 1), m2 = ld4(m + 2);
-                t = rt_hit_sphere(rt_msphere_center(m0, m1, m2, time), m0.w, o, d, tmin, hit.t, code == src);
-                if (STATS) wc->mspheres++;
+        do {  // leaf
+            uint32_t x = ~(uint32_t)cur;
+            if (x & RT_LEAF_INSTANCE_BIT) {
+                int32_t ii = (int32_t)(x & 0x3FFFFFFFu);
+                rt_f4 i0 = ld4(sc.instances + 2 * (size_t)ii), i1 = ld4(sc.instances + 2 * (size_t)ii + 1);
+                if (sp < RT_STACK_DEPTH) stk.set(sp++, RT_SENTINEL);
+                inst = ii;
+                if (STATS) wc->instances++;
+                o = rt_to_object_point(i0, i1, wo); d = rt_to_object_dir(i0, wd);
+                inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
+                cur = f2i(i1.y);
+                break;
             }
-            if (t < hit.t) { hit.t = t; hit.code = code; hit.inst = inst; }  // false for NaN
-        }
-        cur = sp > 0 ? stk.get(--sp) : RT_EMPTY_STACK;
+            uint32_t kind = (x >> 28) & 3u, cnt = ((x >> 26) & 3u) + 1u, first = x & 0x03FFFFFFu;
+            for (uint32_t k = 0; k < cnt; ++k) {
+                uint32_t idx = first + k, code = RT_HIT_CODE(kind, idx);
+                float t;
+                if (kind == RT_KIND_RECT) {
+                    if (STATS) wc->rects++;
+                    if (code == src) continue;
+                    rt_f4 r0 = ld4(sc.rects + 2 * (size_t)idx), r1 = ld4(sc.rects + 2 * (size_t)idx + 1);
+                    t = rt_hit_rect(r0, r1.x, f2i(r1.y), o, d, tmin, hit.t);
+                } else {  // sphere or moving sphere: one intersection path, the centre is the only difference
+                    v3 c; float r;
+                    if (kind == RT_KIND_SPHERE) {
+                        rt_f4 s = ld4(sc.spheres + idx);
+                        c = mk3(s.x, s.y, s.z); r = s.w;
+                        if (STATS) wc->spheres++;
+                    } else {
+                        const rt_f4* m = sc.mspheres + 3 * (size_t)idx;
+                        rt_f4 m0 = ld4(m), m1 = ld4(m + 1), m2 = ld4(m + 2);
+                        c = rt_msphere_center(m0, m1, m2, time); r = m0.w;
+                        if (STATS) wc->mspheres++;
+                    }
+                    t = rt_hit_sphere(c, r, o, d, tmin, hit.t, code == src);
+                }
+                if (t < hit.t) { hit.t = t; hit.code = code; hit.inst = inst; }  // false for NaN
+            }
+            cur = sp > 0 ? stk.get(--sp) : RT_EMPTY_STACK;
+        } while (cur < 0);
     }
 }
 

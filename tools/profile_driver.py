@@ -1,0 +1,23 @@
+"""Small driver for rocprofv3 runs: renders one config for a few passes and prints Mrays/s.
+usage: python3 tools/profile_driver.py <config.yml> <spp> <repeats> [paths_per_pass]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ray_tracing_amd as rt  # noqa: E402
+
+name, spp, reps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+ppp = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+abl = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+path = os.path.join(ROOT, "configs", name)
+cfg = rt.load_config(path)
+b = rt.Builder()
+scene = rt.Scene(b, b.scene_from_config(path, 0x5EED0001), 0)
+cam = rt.camera_from_config(cfg)
+import torch  # noqa: E402  (device buffers only)
+acc = torch.zeros((cfg.image_height, cfg.image_width, 3), dtype=torch.float32, device="cuda:0")
+for i in range(reps):
+    p = rt.render_params(cfg.image_width, cfg.image_height, spp, cfg.max_depth, 0x5EED0002, sample_offset=i * spp, paths_per_pass=ppp, flags=abl << 8)
+    st = scene.render_device(cam, p, acc.data_ptr(), None, None)
+    print("abl %d " % abl + "%s spp %d: %.2f ms, %.1f Mrays/s, bounce loop %.2f ms, passes %d" % (name, spp, st.seconds * 1e3, st.rays / st.seconds / 1e6, st.kernel_ms_extend, st.passes), flush=True)
