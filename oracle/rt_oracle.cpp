@@ -78,8 +78,8 @@ static inline void philox4x32_10(const u32 ctr[4], const u32 key[2], u32 out[4])
 // Per-path draw schedule: dimension `dim` of bounce slot `bounce` for (pixel, sample).
 //   bounce 0 (camera): dim0,1 pixel jitter (main.rs:572-573); dim2,3 lens (cameras.rs:83);
 //                      dim4 shutter time (cameras.rs:86-91)
-//   bounce b>=1      : dim0,1 unit vector (utils.rs:13-22); dim2 dielectric (materials.rs:197);
-//                      dim 4+m the free-flight draw of medium m (mediums.rs:64)
+//   bounce b>=1      : dim0,1 unit vector (utils.rs:13-22); dim0 also decides reflect / refract in a dielectric
+//                      (materials.rs:197; no material uses both); dim 2+m the free-flight draw of medium m (mediums.rs:64)
 // Value = top 24 bits * 2^-24 so that f32 and f64 consumers see the identical number.
 struct Stats;
 struct Ctx {
@@ -288,7 +288,7 @@ struct Dielectric : Material {  // materials.rs:158-210
         double cos_theta = -std::min(dot(ud, h.normal), 1.0);  // materials.rs:190 (min binds before unary minus)
         double sin_theta = std::sqrt(1.0 - cos_theta * cos_theta);
         bool cannot = ratio * sin_theta > 1.0;
-        V3 dir = (cannot || reflectance(cos_theta, ratio) > cx.xi(2)) ? reflect(ud, h.normal)
+        V3 dir = (cannot || reflectance(cos_theta, ratio) > cx.xi(0)) ? reflect(ud, h.normal)
                                                                       : refract(ud, h.normal, ratio);
         out = Ray(h.p, dir, in.time);
         return true;
@@ -495,7 +495,7 @@ struct ConstantMedium : Hittable {  // mediums.rs:14-92
         if (r1.t < 0.0) r1.t = 0.0;
         double len = norm(ray.d);
         double inside = (r2.t - r1.t) * len;
-        double hit_dist = neg_inv_density * std::log10(cx.xi(4 + slot));  // mediums.rs:64 (log base 10)
+        double hit_dist = neg_inv_density * std::log10(cx.xi(2 + slot));  // mediums.rs:64 (log base 10)
         if (hit_dist > inside) return false;
         double t = r1.t + hit_dist / len;
         rec = HitRecord::make(ray.at(t), t, ray, V3(1, 0, 0), phase, 0.0, 0.0, id);

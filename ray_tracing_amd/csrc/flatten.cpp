@@ -252,8 +252,10 @@ private:
     }
     void emit_tables() {
         for (const MatNode& m : b.materials) {
-            out.materials.push_back(f4(i2f(m.type), i2f(m.tex), (float)m.fuzz, (float)m.ir));
-            out.materials.push_back(f4((float)m.albedo[0], (float)m.albedo[1], (float)m.albedo[2], 0));
+            int tex = m.tex; const double* rgb = m.albedo;
+            if (tex >= 0 && b.textures[tex].type == RT_TEX_SOLID) { rgb = b.textures[tex].rgb; tex = -1; }  // bake SolidColor
+            out.materials.push_back(f4(i2f(m.type), i2f(tex), (float)m.fuzz, (float)m.ir));
+            out.materials.push_back(f4((float)rgb[0], (float)rgb[1], (float)rgb[2], 0));
         }
         for (const TexNode& t : b.textures) {
             if (t.type == RT_TEX_CHECKER) { out.textures.push_back(f4(i2f(t.type), i2f(t.even), i2f(t.odd), 0)); out.textures.push_back(f4(0, 0, 0, 0)); }

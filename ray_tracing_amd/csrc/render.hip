@@ -54,7 +54,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev
         counts1[sh * RT_COUNT_STRIDE] = cnt;
     }
     for (uint32_t pid = blockIdx.x * RT_BLOCK + threadIdx.x; pid < n_paths; pid += gridDim.x * RT_BLOCK) {
-        uint32_t pixel = pid % (uint32_t)fr.n_pixels, s = pid / (uint32_t)fr.n_pixels;
+        uint32_t pixel, s;
+        rt_split_path(fr, pid, pixel, s);
         v3 o, d; float time;
         rt_camera_ray(cam, fr, pixel, (uint32_t)fr.sample_base + s, o, d, time);
         rt_f4 a, b, c;
@@ -94,13 +95,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(RtSceneView sc, RtFrameDev 
             v3 o = mk3(a.x, a.y, a.z), d = mk3(b.x, b.y, b.z), beta = mk3(c.x, c.y, c.z);
             float time = a.w;
             uint32_t src = (uint32_t)f2i(b.w), pid = (uint32_t)f2i(c.w);
-            uint32_t pixel = pid % (uint32_t)fr.n_pixels, sample = (uint32_t)fr.sample_base + pid / (uint32_t)fr.n_pixels;
+            uint32_t pixel, sample;
+            rt_split_path(fr, pid, pixel, sample);
+            sample += (uint32_t)fr.sample_base;
+            uint32_t rnd[4];
+            rt_philox(pixel, sample, (uint32_t)bounce, 0u, fr.key0, fr.key1, rnd);
 
             RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
             RtCounters cnt = {0, 0, 0, 0, 0, 0};
             if (ABL & 2) { hit.t = 1.0f; hit.code = RT_HIT_CODE(sc.n_rects > 0 ? RT_KIND_RECT : RT_KIND_SPHERE, pid % 5u); }
             else rt_closest_hit<STATS>(sc, o, d, time, RT_TMIN, src, stk, hit, &cnt);
-            if (!(ABL & 1) && sc.n_media > 0) rt_media_hits(sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, hit);
+            if (!(ABL & 1) && sc.n_media > 0) rt_media_hits(sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, rnd, hit);
             if (STATS) {
                 atomicAdd(work + 0, (unsigned long long)cnt.nodes); atomicAdd(work + 1, (unsigned long long)cnt.spheres);
                 atomicAdd(work + 2, (unsigned long long)cnt.mspheres); atomicAdd(work + 3, (unsigned long long)cnt.rects);
@@ -114,12 +119,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(RtSceneView sc, RtFrameDev 
             } else {
                 RtSurface sf;
                 rt_surface(sc, o, d, time, hit, false, sf);
-                uint32_t rnd[4];
-                rt_philox(pixel, sample, (uint32_t)bounce, 0u, fr.key0, fr.key1, rnd);
                 v3 atten, dir, emitted;
                 bool scattered;
                 if (ABL & 4) { atten = mk3(0.8f, 0.8f, 0.8f); dir = sf.n + mk3(rt_u24(rnd[0]), rt_u24(rnd[1]), rt_u24(rnd[2])); emitted = mk3(0, 0, 0); scattered = rnd[3] > 0x30000000u; }
-                else scattered = rt_scatter(sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), rt_u24(rnd[2]), atten, dir, emitted);
+                else scattered = rt_scatter(sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), atten, dir, emitted);
                 if (STATS) {
                     rt_f4 a0 = ld4(sc.materials + 2 * (size_t)sf.mat);
                     int mtype = f2i(a0.x);
@@ -188,7 +191,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(RtSceneView sc, RtCameraDe
     rt_camera_ray(cam, fr, pixel, sample, o, d, time);
     RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
     rt_closest_hit<false>(sc, o, d, time, RT_TMIN, RT_HIT_NONE, stk, hit, nullptr);
-    if (sc.n_media > 0) rt_media_hits(sc, o, d, time, RT_TMIN, pixel, sample, 1u, fr.key0, fr.key1, hit);
+    if (sc.n_media > 0) {
+        uint32_t rnd[4];
+        rt_philox(pixel, sample, 1u, 0u, fr.key0, fr.key1, rnd);
+        rt_media_hits(sc, o, d, time, RT_TMIN, pixel, sample, 1u, fr.key0, fr.key1, rnd, hit);
+    }
     RtSurface sf; sf.id = -1; sf.n = mk3(0, 0, 0); sf.front = false; sf.u = sf.v = 0.0f;
     if (hit.code != RT_HIT_NONE) rt_surface(sc, o, d, time, hit, true, sf);
     ids[pixel] = sf.id; ts[pixel] = hit.t;
@@ -209,14 +216,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_scatter_rays(RtSceneView sc, const
     uint32_t pixel = pixel0 + (uint32_t)i;
     RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
     rt_closest_hit<false>(sc, o, d, time, RT_TMIN, RT_HIT_NONE, stk, hit, nullptr);
-    if (sc.n_media > 0) rt_media_hits(sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, key0, key1, hit);
+    uint32_t rnd[4]; rt_philox(pixel, sample, (uint32_t)bounce, 0u, key0, key1, rnd);
+    if (sc.n_media > 0) rt_media_hits(sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, key0, key1, rnd, hit);
     float* w = out + 14 * (size_t)i;
     for (int k = 0; k < 14; ++k) w[k] = 0.0f;
     if (hit.code == RT_HIT_NONE) { w[0] = -1.0f; return; }
     RtSurface sf; rt_surface(sc, o, d, time, hit, false, sf);
-    uint32_t rnd[4]; rt_philox(pixel, sample, (uint32_t)bounce, 0u, key0, key1, rnd);
     v3 atten, dir, emitted;
-    bool sc_ok = rt_scatter(sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), rt_u24(rnd[2]), atten, dir, emitted);
+    bool sc_ok = rt_scatter(sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), atten, dir, emitted);
     w[0] = sc_ok ? 1.0f : 0.0f;
     w[1] = emitted.x; w[2] = emitted.y; w[3] = emitted.z; w[4] = atten.x; w[5] = atten.y; w[6] = atten.z;
     w[7] = sf.p.x; w[8] = sf.p.y; w[9] = sf.p.z; w[10] = dir.x; w[11] = dir.y; w[12] = dir.z; w[13] = time;
@@ -292,6 +299,7 @@ static void make_frame(const RtRenderParams* p, RtFrameDev& fr) {
     fr.max_depth = p->max_depth;
     fr.key0 = (uint32_t)p->seed; fr.key1 = (uint32_t)(p->seed >> 32);
     fr.inv_wm1 = (float)(1.0 / (double)(p->width - 1)); fr.inv_hm1 = (float)(1.0 / (double)(p->height - 1));
+    fr.inv_n_pixels = 1.0 / (double)fr.n_pixels;
     for (int c = 0; c < 3; ++c) fr.background[c] = p->background[c];
 }
 static void make_cam(const RtCamera* cam, RtCameraDev& cd) {

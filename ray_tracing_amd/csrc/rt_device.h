@@ -78,6 +78,16 @@ RT_HD v3 normalize3(v3 a) {
     return rt_rcp(rt_sqrt(l2)) * a;
 }
 
+// Marks a value that is the same in every lane of the wave (a record index read from a wave-uniform record):
+// the compiler can then address through SGPRs and fetch with scalar loads instead of 64-lane vector loads.
+RT_HD int rt_uniform(int v) {
+#if RT_ON_DEVICE
+    return __builtin_amdgcn_readfirstlane(v);
+#else
+    return v;
+#endif
+}
+
 RT_HD rt_f4 ld4(const rt_f4* p) {
 #if RT_ON_DEVICE
     const float4 v = *reinterpret_cast<const float4*>(p);
@@ -90,7 +100,8 @@ RT_HD rt_f4 ld4(const rt_f4* p) {
 // ------------------------------------------------------------------ Philox4x32-10
 // Counter (pixel, sample, bounce, block), key = render seed.  Draw schedule:
 //   bounce 0 / block 0: pixel jitter x, y, lens a, lens b     block 1: shutter time
-//   bounce b / block 0: unit-vector u1, u2, dielectric draw   block 1 + m/4, lane m%4: medium m
+//   bounce b: draw k lives in block k/4, lane k%4.  k = 0, 1: unit-vector u1, u2 (a dielectric uses k = 0 for its
+//             reflect-or-refract decision: no material needs both); k = 2 + m: free flight in medium m
 // A draw is the top 24 bits * 2^-24, exactly representable in fp32.
 RT_HD void rt_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
@@ -113,6 +124,15 @@ RT_HD v3 rt_unit_vector(float u1, float u2) {
     float r = rt_sqrt(fmaxf(0.0f, 1.0f - z * z));
     float s, c; rt_sincos_2pi(u2, &s, &c);
     return mk3(r * c, r * s, z);
+}
+
+// Path id = sample_in_pass * n_pixels + pixel.  The quotient comes from one f64 multiply and is exact after one
+// correction step (ids and pixel counts are below 2^32), which is cheaper than a 32-bit integer division.
+RT_HD void rt_split_path(const RtFrameDev& fr, uint32_t pid, uint32_t& pixel, uint32_t& s_local) {
+    uint32_t q = (uint32_t)((double)pid * fr.inv_n_pixels);
+    int64_t r = (int64_t)pid - (int64_t)q * (int64_t)fr.n_pixels;
+    if (r < 0) { q--; r += fr.n_pixels; } else if (r >= fr.n_pixels) { q++; r -= fr.n_pixels; }
+    s_local = q; pixel = (uint32_t)r;
 }
 
 // ------------------------------------------------------------------ camera (cameras.rs:82-98)
@@ -147,14 +167,10 @@ RT_HD void rt_camera_ray(const RtCameraDev& cam, const RtFrameDev& fr, uint32_t 
 // (Haines et al., "Precision improvements for ray/sphere intersection", Ray Tracing Gems ch. 7).
 // `self` = the ray starts on this very sphere: the roots are then exactly {0, 2b'/a}; the zero
 // root is what the reference discards through t_min = 0.001.
-RT_HD float rt_hit_sphere(v3 c, float r, v3 o, v3 d, float tmin, float tmax, bool self) {
+RT_HD bool rt_sphere_roots(v3 c, float r, v3 o, v3 d, float& tn, float& tf) {
     v3 f = o - c;
     float a = dot3(d, d), ia = rt_rcp(a);
     float bp = -dot3(f, d);
-    if (self) {
-        float t = 2.0f * bp * ia;
-        return (bp > 0.0f && t >= tmin && t <= tmax) ? t : rt_nan();
-    }
     float cc = fmaf(-r, r, dot3(f, f));
     float disc;
     if (fabsf(cc) < 0.125f * r * r) {
@@ -167,17 +183,27 @@ RT_HD float rt_hit_sphere(v3 c, float r, v3 o, v3 d, float tmin, float tmax, boo
         double B = -(fx * dx + fy * dy + fz * dz);
         double Cc = fx * fx + fy * fy + fz * fz - rr * rr;
         double D = B * B - A * Cc;
-        if (!(D >= 0.0)) return rt_nan();
+        if (!(D >= 0.0)) return false;
         bp = (float)B; cc = (float)Cc; disc = (float)D;
     } else {
         v3 l = fma3(bp * ia, d, f);
         float delta = fmaf(r, r, -dot3(l, l));
-        if (!(delta >= 0.0f)) return rt_nan();
+        if (!(delta >= 0.0f)) return false;
         disc = a * delta;
     }
     float q = bp + copysignf(rt_sqrt(disc), bp);
     float ta = q * ia, tb = cc * rt_rcp(q);
-    float tn = fminf(ta, tb), tf = fmaxf(ta, tb);
+    tn = fminf(ta, tb); tf = fmaxf(ta, tb);
+    return true;
+}
+RT_HD float rt_hit_sphere(v3 c, float r, v3 o, v3 d, float tmin, float tmax, bool self) {
+    if (self) {
+        float bp = -dot3(o - c, d);
+        float t = 2.0f * bp * rt_rcp(dot3(d, d));
+        return (bp > 0.0f && t >= tmin && t <= tmax) ? t : rt_nan();
+    }
+    float tn, tf;
+    if (!rt_sphere_roots(c, r, o, d, tn, tf)) return rt_nan();
     if (tn >= tmin && tn <= tmax) return tn;
     if (tf >= tmin && tf <= tmax) return tf;
     return rt_nan();
@@ -311,10 +337,14 @@ RT_HD void rt_closest_hit(const RtSceneView& sc, v3 wo, v3 wd, float time, float
 }
 
 // ------------------------------------------------------------------ constant media (mediums.rs:39-87)
+// Every lane tests the same medium at the same time, so all record indices are wave-uniform (rt_uniform) and the
+// boundary data comes in through scalar loads.
+//
 // Closest hit of the boundary's primitives inside [tmin, tmax] (linear scan = objects.rs:67-78).
 RT_HD float rt_boundary_hit(const RtSceneView& sc, rt_f4 m2, rt_f4 m3, v3 o, v3 d, float time, float tmin, float tmax) {
     float best = tmax; bool any = false;
-    int s0 = f2i(m2.y), sn = f2i(m2.z), q0 = f2i(m2.w), qn = f2i(m3.x), r0 = f2i(m3.y), rn = f2i(m3.z);
+    int s0 = rt_uniform(f2i(m2.y)), sn = rt_uniform(f2i(m2.z)), q0 = rt_uniform(f2i(m2.w)), qn = rt_uniform(f2i(m3.x));
+    int r0 = rt_uniform(f2i(m3.y)), rn = rt_uniform(f2i(m3.z));
     for (int i = 0; i < sn; ++i) {
         rt_f4 s = ld4(sc.spheres + s0 + i);
         float t = rt_hit_sphere(mk3(s.x, s.y, s.z), s.w, o, d, tmin, best, false);
@@ -334,38 +364,69 @@ RT_HD float rt_boundary_hit(const RtSceneView& sc, rt_f4 m2, rt_f4 m3, v3 o, v3 
     return any ? best : rt_nan();
 }
 
+// The two smallest boundary crossings of the whole ray line, a <= b (+inf when absent), in one scan.  mediums.rs:46-47
+// asks for try_hit(-inf, inf) and then try_hit(t1 + 0.0001, inf): the first is the smallest crossing and the second
+// the smallest crossing that is >= t1 + 0.0001, which is b unless two crossings coincide (ray through an edge).
+RT_HD void rt_boundary_pair(const RtSceneView& sc, rt_f4 m2, rt_f4 m3, v3 o, v3 d, float time, float& a, float& b) {
+    a = rt_inf(); b = rt_inf();
+    int s0 = rt_uniform(f2i(m2.y)), sn = rt_uniform(f2i(m2.z)), q0 = rt_uniform(f2i(m2.w)), qn = rt_uniform(f2i(m3.x));
+    int r0 = rt_uniform(f2i(m3.y)), rn = rt_uniform(f2i(m3.z));
+#define RT_INSERT(t_) do { float t__ = (t_); if (t__ < a) { b = a; a = t__; } else if (t__ < b) b = t__; } while (0)
+    for (int i = 0; i < sn; ++i) {
+        rt_f4 s = ld4(sc.spheres + s0 + i);
+        float tn, tf;
+        if (rt_sphere_roots(mk3(s.x, s.y, s.z), s.w, o, d, tn, tf)) { RT_INSERT(tn); RT_INSERT(tf); }
+    }
+    for (int i = 0; i < qn; ++i) {
+        const rt_f4* m = sc.mspheres + 3 * (size_t)(q0 + i);
+        rt_f4 ma = ld4(m), mb = ld4(m + 1), mc = ld4(m + 2);
+        float tn, tf;
+        if (rt_sphere_roots(rt_msphere_center(ma, mb, mc, time), ma.w, o, d, tn, tf)) { RT_INSERT(tn); RT_INSERT(tf); }
+    }
+    for (int i = 0; i < rn; ++i) {
+        rt_f4 ra = ld4(sc.rects + 2 * (size_t)(r0 + i)), rb = ld4(sc.rects + 2 * (size_t)(r0 + i) + 1);
+        float t = rt_hit_rect(ra, rb.x, f2i(rb.y), o, d, -rt_inf(), rt_inf());
+        if (t == t) RT_INSERT(t);
+    }
+#undef RT_INSERT
+}
+
 // Tests every medium against the segment [tmin, hit.t]; a free-flight collision that lands before
 // the current closest hit replaces it.  With one fixed draw per (medium, segment) the outcome does
 // not depend on the order in which the reference's BVH would have visited the medium.
+// rnd0 = Philox block 0 of this bounce (its lanes 2, 3 are the draws of media 0, 1).
 RT_HD void rt_media_hits(const RtSceneView& sc, v3 wo, v3 wd, float time, float tmin, uint32_t pixel, uint32_t sample,
-                         uint32_t bounce, uint32_t key0, uint32_t key1, RtHit& hit) {
-    uint32_t rnd[4] = {0, 0, 0, 0};
+                         uint32_t bounce, uint32_t key0, uint32_t key1, const uint32_t rnd0[4], RtHit& hit) {
+    uint32_t rnd[4] = {rnd0[0], rnd0[1], rnd0[2], rnd0[3]};
     float len = rt_sqrt(dot3(wd, wd));
+    v3 winv = mk3(rt_rcp(wd.x), rt_rcp(wd.y), rt_rcp(wd.z));
     for (int m = 0; m < sc.n_media; ++m) {
-        if ((m & 3) == 0) rt_philox(pixel, sample, bounce, 1u + (uint32_t)(m >> 2), key0, key1, rnd);
+        int k = m + 2;
+        if (k >= 4 && (k & 3) == 0) rt_philox(pixel, sample, bounce, (uint32_t)(k >> 2), key0, key1, rnd);
         const rt_f4* md = sc.media + 4 * (size_t)m;
         rt_f4 m0 = ld4(md), m1 = ld4(md + 1);
-        v3 inv = mk3(rt_rcp(wd.x), rt_rcp(wd.y), rt_rcp(wd.z));
-        if (!(rt_slab(m0.x, m0.y, m0.z, m1.x, m1.y, m1.z, wo, inv, tmin, hit.t) < rt_inf())) continue;
+        if (!(rt_slab(m0.x, m0.y, m0.z, m1.x, m1.y, m1.z, wo, winv, tmin, hit.t) < rt_inf())) continue;
         rt_f4 m2 = ld4(md + 2), m3 = ld4(md + 3);
         v3 o = wo, d = wd;
-        int ii = f2i(m2.x);
+        int ii = rt_uniform(f2i(m2.x));
         if (ii >= 0) {
             rt_f4 i0 = ld4(sc.instances + 2 * (size_t)ii), i1 = ld4(sc.instances + 2 * (size_t)ii + 1);
             o = rt_to_object_point(i0, i1, wo); d = rt_to_object_dir(i0, wd);
         }
-        float t1 = rt_boundary_hit(sc, m2, m3, o, d, time, -rt_inf(), rt_inf());   // mediums.rs:46
-        if (!(t1 == t1)) continue;
-        // mediums.rs:47 asks for the next boundary hit after t1 + 0.0001; in fp32 that offset vanishes once
-        // |t1| exceeds ~1000 (the r = 5000 fog), so it is widened to a few ulps of t1 when larger.
-        float t2 = rt_boundary_hit(sc, m2, m3, o, d, time, t1 + fmaxf(0.0001f, 1e-6f * fabsf(t1)), rt_inf());
-        if (!(t2 == t2)) continue;
+        float t1, t2;
+        rt_boundary_pair(sc, m2, m3, o, d, time, t1, t2);                           // mediums.rs:46-47
+        if (!(t1 < rt_inf())) continue;
+        // The re-query offset 0.0001 vanishes in fp32 once |t1| exceeds ~1000 (the r = 5000 fog), so it is widened
+        // to a few ulps of t1 when that is larger.
+        float t_next = t1 + fmaxf(0.0001f, 1e-6f * fabsf(t1));
+        if (t2 < t_next) t2 = rt_boundary_hit(sc, m2, m3, o, d, time, t_next, rt_inf());
+        if (!(t2 < rt_inf())) continue;                                             // also false for NaN (no second crossing)
         if (t1 < tmin) t1 = tmin;
         if (t2 > hit.t) t2 = hit.t;
         if (t1 >= t2) continue;
         if (t1 < 0.0f) t1 = 0.0f;
         float inside = (t2 - t1) * len;
-        float hit_dist = m0.w * rt_log10(rt_u24(rnd[m & 3]));                      // mediums.rs:64 (log base 10)
+        float hit_dist = m0.w * rt_log10(rt_u24(rnd[k & 3]));                       // mediums.rs:64 (log base 10)
         if (hit_dist > inside) continue;
         float t = t1 + hit_dist * rt_rcp(len);
         if (t < hit.t) { hit.t = t; hit.code = RT_HIT_CODE(RT_KIND_MEDIUM, (uint32_t)m); hit.inst = -1; }
@@ -466,7 +527,9 @@ RT_HD float rt_turbulence(const rt_f4* vec, const uint8_t* perm, v3 p) {  // tex
     for (int i = 0; i < 7; ++i) { accum = fmaf(weight, rt_perlin_noise(vec, perm, p), accum); weight *= 0.5f; p = 2.0f * p; }
     return fabsf(accum);
 }
-RT_HD v3 rt_texture_value(const RtSceneView& sc, int tex, v3 p) {
+// `inline_rgb` is the colour baked into the material record when its texture is a SolidColor (tex < 0).
+RT_HD v3 rt_texture_value(const RtSceneView& sc, int tex, v3 inline_rgb, v3 p) {
+    if (tex < 0) return inline_rgb;
     for (int it = 0; it < 16; ++it) {
         rt_f4 t0 = ld4(sc.textures + 2 * (size_t)tex), t1 = ld4(sc.textures + 2 * (size_t)tex + 1);
         int type = f2i(t0.x);
@@ -490,25 +553,25 @@ RT_HD v3 rt_texture_value(const RtSceneView& sc, int tex, v3 p) {
 // ------------------------------------------------------------------ materials (materials.rs)
 RT_HD v3 rt_reflect(v3 v, v3 n) { return fma3(-2.0f * dot3(v, n), n, v); }  // utils.rs:87-89
 
-// One scatter event (lib.rs:64-65).  u1,u2: unit-vector draws, u3: dielectric draw.
+// One scatter event (lib.rs:64-65).  u1, u2: the bounce's two draws (unit vector; a dielectric decides on u1).
 // Returns true when the path continues along `dir` with throughput *= atten.
-RT_HD bool rt_scatter(const RtSceneView& sc, const RtSurface& s, v3 wd, float u1, float u2, float u3,
+RT_HD bool rt_scatter(const RtSceneView& sc, const RtSurface& s, v3 wd, float u1, float u2,
                       v3& atten, v3& dir, v3& emitted) {
-    rt_f4 a0 = ld4(sc.materials + 2 * (size_t)s.mat);
+    rt_f4 a0 = ld4(sc.materials + 2 * (size_t)s.mat), a1 = ld4(sc.materials + 2 * (size_t)s.mat + 1);
     int type = f2i(a0.x), tex = f2i(a0.y);
+    v3 rgb = mk3(a1.x, a1.y, a1.z);
     emitted = mk3(0, 0, 0);
     atten = mk3(1, 1, 1);
     dir = s.n;
     if (type == RT_MAT_LAMBERTIAN) {  // materials.rs:77-90
         dir = s.n + rt_unit_vector(u1, u2);
         if (dot3(dir, dir) < 1e-16f) dir = s.n;
-        atten = rt_texture_value(sc, tex, s.p);
+        atten = rt_texture_value(sc, tex, rgb, s.p);
         return true;
     }
     if (type == RT_MAT_METAL) {  // materials.rs:129-145
-        rt_f4 a1 = ld4(sc.materials + 2 * (size_t)s.mat + 1);
         dir = fma3(a0.z, rt_unit_vector(u1, u2), rt_reflect(normalize3(wd), s.n));
-        atten = mk3(a1.x, a1.y, a1.z);
+        atten = rgb;
         return dot3(dir, s.n) > 0.0f;
     }
     if (type == RT_MAT_DIELECTRIC) {  // materials.rs:181-209
@@ -520,7 +583,7 @@ RT_HD bool rt_scatter(const RtSceneView& sc, const RtSurface& s, v3 wd, float u1
         float r0 = (1.0f - ratio) * rt_rcp(1.0f + ratio); r0 *= r0;  // materials.rs:174-178
         float om = 1.0f - cos_theta, om2 = om * om;
         float refl = fmaf(1.0f - r0, om2 * om2 * om, r0);
-        if (cannot || refl > u3) dir = rt_reflect(ud, s.n);
+        if (cannot || refl > u1) dir = rt_reflect(ud, s.n);
         else {  // utils.rs:79-84
             v3 perp = ratio * fma3(cos_theta, s.n, ud);
             float par = -rt_sqrt(fabsf(1.0f - dot3(perp, perp)));
@@ -529,11 +592,11 @@ RT_HD bool rt_scatter(const RtSceneView& sc, const RtSurface& s, v3 wd, float u1
         return true;
     }
     if (type == RT_MAT_LIGHT) {  // materials.rs:243-249
-        emitted = rt_texture_value(sc, tex, s.p);
+        emitted = rt_texture_value(sc, tex, rgb, s.p);
         return false;
     }
     // Isotropic, materials.rs:276-283
     dir = rt_unit_vector(u1, u2);
-    atten = rt_texture_value(sc, tex, s.p);
+    atten = rt_texture_value(sc, tex, rgb, s.p);
     return true;
 }

@@ -57,7 +57,8 @@ enum { RT_OP_TRANSLATE = 0, RT_OP_ROTATE_Y = 1 };
 #define RT_MEDIUM_F4 4
 
 // ---- material (materials.rs), 2 x f4:
-//   a0 = int/float (type, texture index, fuzz, ir)     a1 = (albedo rgb for Metal, 0)
+//   a0 = int/float (type, texture index or -1, fuzz, ir)     a1 = (rgb, 0): Metal albedo, or the colour of a
+//   SolidColor texture baked in (texture index -1) so that the common case needs no texture fetch
 enum { RT_MAT_LAMBERTIAN = 0, RT_MAT_METAL = 1, RT_MAT_DIELECTRIC = 2, RT_MAT_LIGHT = 3, RT_MAT_ISOTROPIC = 4 };
 #define RT_MATERIAL_F4 2
 
@@ -100,6 +101,7 @@ struct RtFrameDev {
     int32_t max_depth;
     uint32_t key0, key1;     // Philox key = render seed
     float inv_wm1, inv_hm1;  // 1/(W-1), 1/(H-1)   main.rs:572-573
+    double inv_n_pixels;     // for path id -> (sample, pixel) without an integer divide
     float background[3];
 };
 

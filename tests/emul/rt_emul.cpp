@@ -26,6 +26,7 @@ static void make_frame(const RtRenderParams* p, RtFrameDev& fr) {
     fr.width = p->width; fr.height = p->height; fr.n_pixels = p->width * p->height; fr.max_depth = p->max_depth;
     fr.key0 = (uint32_t)p->seed; fr.key1 = (uint32_t)(p->seed >> 32);
     fr.inv_wm1 = (float)(1.0 / (double)(p->width - 1)); fr.inv_hm1 = (float)(1.0 / (double)(p->height - 1));
+    fr.inv_n_pixels = 1.0 / (double)fr.n_pixels;
     for (int c = 0; c < 3; ++c) fr.background[c] = p->background[c];
     fr.sample_base = p->sample_offset; fr.spp_chunk = p->spp;
 }
@@ -47,7 +48,10 @@ void emul_trace_primary(const RtSceneView* sc, const RtCamera* cam, const RtRend
         ArrStack stk;
         RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
         rt_closest_hit<false>(*sc, o, d, time, RT_TMIN, RT_HIT_NONE, stk, hit, nullptr);
-        if (sc->n_media > 0) rt_media_hits(*sc, o, d, time, RT_TMIN, pixel, (uint32_t)sample, 1u, fr.key0, fr.key1, hit);
+        if (sc->n_media > 0) {
+            uint32_t rnd[4]; rt_philox(pixel, (uint32_t)sample, 1u, 0u, fr.key0, fr.key1, rnd);
+            rt_media_hits(*sc, o, d, time, RT_TMIN, pixel, (uint32_t)sample, 1u, fr.key0, fr.key1, rnd, hit);
+        }
         RtSurface sf; sf.id = -1; sf.n = mk3(0, 0, 0); sf.front = false; sf.u = sf.v = 0;
         if (hit.code != RT_HIT_NONE) rt_surface(*sc, o, d, time, hit, true, sf);
         ids[pixel] = sf.id; ts[pixel] = hit.t;
@@ -77,12 +81,12 @@ void emul_render(const RtSceneView* sc, const RtCamera* cam, const RtRenderParam
                     ArrStack stk;
                     RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
                     rt_closest_hit<false>(*sc, o, d, time, RT_TMIN, src, stk, hit, nullptr);
-                    if (sc->n_media > 0) rt_media_hits(*sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, hit);
+                    uint32_t rnd[4]; rt_philox(pixel, sample, (uint32_t)bounce, 0u, fr.key0, fr.key1, rnd);
+                    if (sc->n_media > 0) rt_media_hits(*sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, rnd, hit);
                     if (hit.code == RT_HIT_NONE) { L = L + beta * mk3(fr.background[0], fr.background[1], fr.background[2]); break; }
                     RtSurface sf; rt_surface(*sc, o, d, time, hit, false, sf);
-                    uint32_t rnd[4]; rt_philox(pixel, sample, (uint32_t)bounce, 0u, fr.key0, fr.key1, rnd);
                     v3 atten, dir, emitted;
-                    bool ok = rt_scatter(*sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), rt_u24(rnd[2]), atten, dir, emitted);
+                    bool ok = rt_scatter(*sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), atten, dir, emitted);
                     L = L + beta * emitted;
                     if (!ok) break;
                     beta = beta * atten; o = sf.p; d = dir;
@@ -110,14 +114,14 @@ void emul_scatter_rays(const RtSceneView* sc, const float* rays, int32_t n, uint
         ArrStack stk;
         RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
         rt_closest_hit<false>(*sc, o, d, time, RT_TMIN, RT_HIT_NONE, stk, hit, nullptr);
-        if (sc->n_media > 0) rt_media_hits(*sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, key0, key1, hit);
+        uint32_t rnd[4]; rt_philox(pixel, sample, (uint32_t)bounce, 0u, key0, key1, rnd);
+        if (sc->n_media > 0) rt_media_hits(*sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, key0, key1, rnd, hit);
         float* w = out + 14 * (size_t)i;
         for (int k = 0; k < 14; ++k) w[k] = 0.0f;
         if (hit.code == RT_HIT_NONE) { w[0] = -1.0f; continue; }
         RtSurface sf; rt_surface(*sc, o, d, time, hit, false, sf);
-        uint32_t rnd[4]; rt_philox(pixel, sample, (uint32_t)bounce, 0u, key0, key1, rnd);
         v3 atten, dir, emitted;
-        bool ok = rt_scatter(*sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), rt_u24(rnd[2]), atten, dir, emitted);
+        bool ok = rt_scatter(*sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), atten, dir, emitted);
         w[0] = ok ? 1.0f : 0.0f;
         w[1] = emitted.x; w[2] = emitted.y; w[3] = emitted.z; w[4] = atten.x; w[5] = atten.y; w[6] = atten.z;
         w[7] = sf.p.x; w[8] = sf.p.y; w[9] = sf.p.z; w[10] = dir.x; w[11] = dir.y; w[12] = dir.z; w[13] = time;
