@@ -99,7 +99,7 @@ int rt_scene_create(const RtBuilder* b, RtObj world, int device, RtScene** out);
 void rt_scene_destroy(RtScene* s);
 typedef struct RtSceneInfo {
     int32_t n_nodes, n_spheres, n_moving_spheres, n_rects, n_instances, n_media, n_materials, n_textures, n_perlin;
-    int32_t tlas_depth, blas_depth, max_stack, n_objects, device;
+    int32_t tlas_depth, blas_depth, max_stack, n_objects, device, n_boxes;  /* n_boxes: BoxObj kept as one 6-sided primitive */
     double world_box[6];
     uint64_t device_bytes;
 } RtSceneInfo;
@@ -129,20 +129,22 @@ typedef struct RtRenderParams {
 } RtRenderParams;
 #define RT_FLAG_SUMSQ 1         /* also accumulate per-channel sum of squares (accum_sq must be given) */
 #define RT_FLAG_COUNTERS 2      /* run the instrumented (slower) kernel build and fill RtStats.work */
-#define RT_FLAG_ABLATE_SHIFT 8  /* bits 8..10: timing-only ablation builds (WRONG images): 1 no media, 2 no traversal, 4 no scatter */
+#define RT_FLAG_TIME_TRACE 4    /* bracket every closest-hit launch with HIP events and fill RtStats.kernel_ms_trace */
 
 typedef struct RtStats {
     uint64_t rays;              /* ray segments = executions of src/lib.rs:63 */
     uint64_t paths;             /* width * height * spp */
     uint64_t rays_per_bounce[64]; /* [b-1] = segments traced at bounce b (clamped to 64 entries) */
     double seconds;             /* wall time inside the call (device work, synchronised) */
-    double kernel_ms_extend;    /* summed device time of the closest-hit + scatter kernel (HIP events) */
-    uint64_t extend_launches;
+    double kernel_ms_extend;    /* summed device time of the bounce loops: closest-hit + shade kernels (HIP events) */
+    uint64_t extend_launches;   /* bounces launched (one closest-hit and one shade launch each) */
     int32_t passes;
     /* RT_FLAG_COUNTERS only: [0] BVH nodes visited (2 slab tests each), [1] sphere, [2] moving-sphere, [3] rectangle tests,
-     * [4] instance entries, [5] medium tests, [6] misses, [8..12] scatter evaluations per material kind (Lambertian, Metal,
+     * [4] instance entries, [5] medium tests, [6] misses, [7] box tests, [8..12] scatter evaluations per material kind (Lambertian, Metal,
      * Dielectric, DiffuseLight, Isotropic), [13] Noise-textured, [14] Checker-textured shades. */
     uint64_t work[16];
+    double kernel_ms_trace;     /* RT_FLAG_TIME_TRACE only: summed device time of the closest-hit kernel alone */
+    uint64_t trace_launches;
 } RtStats;
 
 /* Renders `spp` samples of every pixel and ADDS the per-pixel colour sums (src/main.rs:585-589) to

@@ -17,6 +17,7 @@ _lib = None
 
 RT_FLAG_SUMSQ = 1
 RT_FLAG_COUNTERS = 2
+RT_FLAG_TIME_TRACE = 4
 RECT_XY, RECT_XZ, RECT_YZ = 0, 1, 2   # RectangleType, src/objects.rs:339-343
 
 
@@ -37,7 +38,7 @@ class RtConfig(C.Structure):
 class RtSceneInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_nodes", "n_spheres", "n_moving_spheres", "n_rects", "n_instances",
                                          "n_media", "n_materials", "n_textures", "n_perlin", "tlas_depth",
-                                         "blas_depth", "max_stack", "n_objects", "device")] + \
+                                         "blas_depth", "max_stack", "n_objects", "device", "n_boxes")] + \
                [("world_box", C.c_double * 6), ("device_bytes", C.c_uint64)]
 
 
@@ -56,7 +57,7 @@ class RtRenderParams(C.Structure):
 class RtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("rays_per_bounce", C.c_uint64 * 64),
                 ("seconds", C.c_double), ("kernel_ms_extend", C.c_double), ("extend_launches", C.c_uint64),
-                ("passes", C.c_int32), ("work", C.c_uint64 * 16)]
+                ("passes", C.c_int32), ("work", C.c_uint64 * 16), ("kernel_ms_trace", C.c_double), ("trace_launches", C.c_uint64)]
 
 
 # name -> (restype, argtypes); every symbol include/rt_hip.h declares

@@ -39,7 +39,8 @@ struct Box3 {
 struct Op { int type; double a, b, c; };  // translate: offset xyz | rotate_y: cos, sin
 struct PrimRef { int obj; int chain; };
 struct MediumRef { int obj; int chain; std::vector<PrimRef> boundary; };
-struct Item { Box3 box; double cen[3]; int cls; int ref; };  // cls 0..2 = primitive kind, 3 = instance
+struct Item { Box3 box; double cen[3]; int cls; int ref; };  // cls 0..3 = primitive kind, kInstanceClass = instance
+const int kInstanceClass = 7;
 
 float f_down(double v) { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity()); return f; }
 float f_up(double v) { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity()); return f; }
@@ -74,7 +75,7 @@ public:
             int root = build_root(items, kBlasBudget, depth);
             max_blas = std::max(max_blas, depth);
             Box3 wb = chain_world_box(node_box(root), chains[c]);
-            Item it; it.box = wb; it.cls = 3; it.ref = emit_instance((int)c, root);
+            Item it; it.box = wb; it.cls = kInstanceClass; it.ref = emit_instance((int)c, root);
             for (int a = 0; a < 3; ++a) it.cen[a] = 0.5 * (wb.mn[a] + wb.mx[a]);
             top.push_back(it);
         }
@@ -91,6 +92,7 @@ public:
         }
         out.max_stack = out.tlas_depth + (out.instances.empty() ? 0 : 1 + max_blas);
         if (out.max_stack > RT_STACK_DEPTH) return fail("flatten: BVH deeper than the traversal stack");
+        relabel_breadth_first();
         if (!err.empty()) return false;
         return true;
     }
@@ -110,12 +112,13 @@ private:
         if (depth > 4096) return fail("flatten: object graph too deep (cycle?)");
         const ObjNode& o = b.objects[oi];
         switch (o.type) {
+        case OBJ_BOX:  // the six sides stay together as one box primitive
         case OBJ_SPHERE: case OBJ_MSPHERE: case OBJ_RECT: {
             PrimRef p = {oi, chain};
             if (sink) sink->push_back(p); else chain_prims[chain].push_back(p);
             return true;
         }
-        case OBJ_BOX: case OBJ_LIST: case OBJ_BVH:
+        case OBJ_LIST: case OBJ_BVH:
             for (int c : o.children) if (!walk(c, chain, sink, depth + 1)) return false;
             return true;
         case OBJ_TRANSLATE: case OBJ_ROTATE_Y: {
@@ -155,6 +158,8 @@ private:
                 double c[3] = {o.p[0] + s * (o.p[3] - o.p[0]), o.p[1] + s * (o.p[4] - o.p[1]), o.p[2] + s * (o.p[5] - o.p[2])};
                 bx.grow_pt(c[0] - r, c[1] - r, c[2] - r); bx.grow_pt(c[0] + r, c[1] + r, c[2] + r);
             }
+        } else if (o.type == OBJ_BOX) {  // objects.rs:514-516
+            bx.grow_pt(o.p[0], o.p[1], o.p[2]); bx.grow_pt(o.p[3], o.p[4], o.p[5]);
         } else {  // objects.rs:413-429
             const double off = 0.0001;
             double x0 = o.p[0], x1 = o.p[1], y0 = o.p[2], y1 = o.p[3], k = o.p[4];
@@ -184,7 +189,7 @@ private:
     Item prim_item(const PrimRef& p) const {
         const ObjNode& o = b.objects[p.obj];
         Item it; it.box = prim_box(o);
-        it.cls = o.type == OBJ_SPHERE ? RT_KIND_SPHERE : (o.type == OBJ_MSPHERE ? RT_KIND_MSPHERE : RT_KIND_RECT);
+        it.cls = o.type == OBJ_SPHERE ? RT_KIND_SPHERE : (o.type == OBJ_MSPHERE ? RT_KIND_MSPHERE : (o.type == OBJ_BOX ? RT_KIND_BOX : RT_KIND_RECT));
         it.ref = p.obj;
         for (int a = 0; a < 3; ++a) it.cen[a] = 0.5 * (it.box.mn[a] + it.box.mx[a]);
         return it;
@@ -203,6 +208,11 @@ private:
             out.mspheres.push_back(f4((float)(o.p[3] - o.p[0]), (float)(o.p[4] - o.p[1]), (float)(o.p[5] - o.p[2]), (float)o.p[6]));
             out.mspheres.push_back(f4((float)(1.0 / (o.p[7] - o.p[6])), 0, 0, 0));
             out.msphere_meta.push_back(meta); return (int)out.msphere_meta.size() - 1;
+        }
+        if (o.type == OBJ_BOX) {
+            out.boxes.push_back(f4((float)o.p[0], (float)o.p[1], (float)o.p[2], i2f(o.mat)));
+            out.boxes.push_back(f4((float)o.p[3], (float)o.p[4], (float)o.p[5], i2f(o.id)));
+            return (int)out.boxes.size() / 2 - 1;
         }
         out.rects.push_back(f4((float)o.p[0], (float)o.p[1], (float)o.p[2], (float)o.p[3]));
         out.rects.push_back(f4((float)o.p[4], i2f(o.rect_type), 0, 0));
@@ -231,8 +241,9 @@ private:
     bool emit_medium(const MediumRef& m) {
         const ObjNode& o = b.objects[m.obj];
         Box3 bx;
-        int first[3] = {(int)out.spheres.size(), (int)out.msphere_meta.size(), (int)out.rect_meta.size()}, count[3] = {0, 0, 0};
-        for (int kind = 0; kind < 3; ++kind)
+        int first[4] = {(int)out.spheres.size(), (int)out.msphere_meta.size(), (int)out.rect_meta.size(), (int)out.boxes.size() / 2};
+        int count[4] = {0, 0, 0, 0};
+        for (int kind = 0; kind < 4; ++kind)
             for (const PrimRef& p : m.boundary) {
                 Item it = prim_item(p);
                 if (it.cls != kind) continue;
@@ -248,6 +259,7 @@ private:
         out.media.push_back(f4(f_up(bx.mx[0] + pad[0]), f_up(bx.mx[1] + pad[1]), f_up(bx.mx[2] + pad[2]), i2f(o.mat)));
         out.media.push_back(f4(i2f(inst), i2f(first[0]), i2f(count[0]), i2f(first[1])));
         out.media.push_back(f4(i2f(count[1]), i2f(first[2]), i2f(count[2]), i2f(o.id)));
+        out.media.push_back(f4(i2f(first[3]), i2f(count[3]), 0, 0));
         return true;
     }
     void emit_tables() {
@@ -268,6 +280,48 @@ private:
         }
     }
 
+    // Renumbers the inner nodes breadth-first from the top-level root (then from each instance's root), so that
+    // "the first K nodes" are the top levels of the tree: the kernels keep that prefix in LDS.
+    void relabel_breadth_first() {
+        const int n = (int)out.nodes.size() / 4;
+        if (n == 0) return;
+        std::vector<int> seeds;
+        if (out.root >= 0) seeds.push_back(out.root);
+        for (size_t i = 0; i < out.instances.size() / RT_INSTANCE_F4; ++i) {
+            int32_t r; std::memcpy(&r, &out.instances[i * RT_INSTANCE_F4 + 1].y, 4);
+            if (r >= 0) seeds.push_back(r);
+        }
+        std::vector<int> new_of(n, -1), order; order.reserve(n);
+        for (int seed : seeds) {
+            if (new_of[seed] >= 0) continue;
+            size_t head = order.size();
+            new_of[seed] = (int)order.size(); order.push_back(seed);
+            while (head < order.size()) {
+                int node = order[head++];
+                for (int c = 0; c < 2; ++c) {
+                    int32_t child; std::memcpy(&child, c == 0 ? &out.nodes[(size_t)node * 4 + 3].x : &out.nodes[(size_t)node * 4 + 3].y, 4);
+                    if (child >= 0 && new_of[child] < 0) { new_of[child] = (int)order.size(); order.push_back(child); }
+                }
+            }
+        }
+        for (int i = 0; i < n; ++i) if (new_of[i] < 0) { new_of[i] = (int)order.size(); order.push_back(i); }  // unreachable nodes keep a slot
+        std::vector<rt_f4> nodes(out.nodes.size());
+        for (int i = 0; i < n; ++i) {
+            int old = order[i];
+            for (int k = 0; k < 4; ++k) nodes[(size_t)i * 4 + k] = out.nodes[(size_t)old * 4 + k];
+            int32_t cl, cr; std::memcpy(&cl, &nodes[(size_t)i * 4 + 3].x, 4); std::memcpy(&cr, &nodes[(size_t)i * 4 + 3].y, 4);
+            if (cl >= 0) cl = new_of[cl];
+            if (cr >= 0) cr = new_of[cr];
+            nodes[(size_t)i * 4 + 3].x = i2f(cl); nodes[(size_t)i * 4 + 3].y = i2f(cr);
+        }
+        out.nodes.swap(nodes);
+        if (out.root >= 0) out.root = new_of[out.root];
+        for (size_t i = 0; i < out.instances.size() / RT_INSTANCE_F4; ++i) {
+            int32_t r; std::memcpy(&r, &out.instances[i * RT_INSTANCE_F4 + 1].y, 4);
+            if (r >= 0) out.instances[i * RT_INSTANCE_F4 + 1].y = i2f(new_of[r]);
+        }
+    }
+
     // ---- BVH build
     int new_node() { for (int i = 0; i < 4; ++i) out.nodes.push_back(f4(0, 0, 0, 0)); return (int)out.nodes.size() / 4 - 1; }
     void set_node(int n, const Box3& l, const Box3& r, int cl, int cr) {
@@ -284,7 +338,7 @@ private:
         return bx;
     }
     int make_leaf(std::vector<Item>& items, size_t lo, size_t hi) {
-        if (items[lo].cls == 3) return rt_leaf_instance(items[lo].ref);
+        if (items[lo].cls == kInstanceClass) return rt_leaf_instance(items[lo].ref);
         int first = -1;
         for (size_t i = lo; i < hi; ++i) { int idx = emit_prim(items[i].ref); if (first < 0) first = idx; }
         return rt_leaf_prims(items[lo].cls, first, (int)(hi - lo));
@@ -292,7 +346,7 @@ private:
     static bool leafable(const std::vector<Item>& items, size_t lo, size_t hi) {
         if (hi - lo > RT_LEAF_MAX_PRIMS) return false;
         for (size_t i = lo + 1; i < hi; ++i) if (items[i].cls != items[lo].cls) return false;
-        return items[lo].cls != 3 || hi - lo == 1;
+        return items[lo].cls != kInstanceClass || hi - lo == 1;
     }
     // Returns a child code for items[lo,hi): a leaf code (<0) or a node index.  `depth` = inner nodes
     // above this subtree; max_depth tracks the deepest inner-node path.
@@ -373,13 +427,13 @@ RtSceneView FlatScene::view() const {
     v.nodes = nodes.data(); v.spheres = spheres.data(); v.sphere_meta = sphere_meta.data();
     v.mspheres = mspheres.data(); v.msphere_meta = msphere_meta.data(); v.rects = rects.data(); v.rect_meta = rect_meta.data();
     v.instances = instances.data(); v.ops = ops.data(); v.media = media.data(); v.materials = materials.data();
-    v.textures = textures.data(); v.perlin_vec = perlin_vec.data(); v.perlin_perm = perlin_perm.data();
+    v.textures = textures.data(); v.perlin_vec = perlin_vec.data(); v.perlin_perm = perlin_perm.data(); v.boxes = boxes.data();
     v.root = root;
     v.n_nodes = (int)nodes.size() / 4; v.n_spheres = (int)spheres.size(); v.n_mspheres = (int)msphere_meta.size();
     v.n_rects = (int)rect_meta.size(); v.n_instances = (int)instances.size() / RT_INSTANCE_F4; v.n_ops = (int)ops.size();
     v.n_media = (int)media.size() / RT_MEDIUM_F4; v.n_materials = (int)materials.size() / RT_MATERIAL_F4;
     v.n_textures = (int)textures.size() / RT_TEXTURE_F4; v.n_perlin = (int)perlin_vec.size() / RT_PERLIN_VEC_F4;
-    v.max_stack = max_stack;
+    v.max_stack = max_stack; v.n_boxes = (int)boxes.size() / 2;
     return v;
 }
 

@@ -2,10 +2,11 @@
 //
 // Wavefront organisation of one pass over P = W*H*spp_chunk paths (replaces src/main.rs:567-599):
 //   k_raygen      : Philox camera rays (pixel jitter, lens, shutter time) -> ray queue 0
-//   k_bounce x D  : for every queued ray: closest hit (two-level BVH + media), scatter, and append of
-//                   the scattered ray to the other queue through a wave-aggregated atomic (one
-//                   atomic per 64-lane wave, ranks from ballot + mbcnt); terminated paths add their
-//                   radiance to their private slot of the contribution buffer
+//   per bounce    : k_trace  closest surface hit of every queued ray (two-level BVH, top levels in LDS, persistent
+//                            waves that refill finished lanes with new rays) -> hit record per ray
+//                   k_shade  media, hit record, emission, scatter; append of the scattered ray to the other queue
+//                            through a wave-aggregated atomic (one atomic per 64-lane wave, ranks from ballot +
+//                            mbcnt); terminated paths add their radiance to their slot of the contribution buffer
 //   k_accumulate  : per pixel, sums the pass's contributions in sample order into the caller's
 //                   accumulation buffer (deterministic; no float atomics anywhere)
 // A ray queue is RT_SHARDS regions of `cap` slots, each with its own counter: a single append counter saturates
@@ -17,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -38,9 +40,10 @@
 
 // ------------------------------------------------------------------ device side
 struct LdsStack {  // one column of the block's LDS stack: entry i of thread t lives at [i][t]
-    int* base;
+    int* base; int depth;
     __host__ __device__ void set(int i, int v) { base[i * RT_BLOCK] = v; }
     __host__ __device__ int get(int i) const { return base[i * RT_BLOCK]; }
+    __host__ __device__ int cap() const { return depth; }
 };
 
 __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev fr, uint32_t n_paths, uint32_t cap, uint32_t* counts1,
@@ -70,20 +73,106 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev
     }
 }
 
-// One bounce for every ray of the input queue (lib.rs:63-71, iteratively).  STATS = true is the instrumented
-// build that also counts node visits / primitive tests / shades into `work` (16 x u64).
-// ABL is a timing-only ablation mask (results are wrong when non-zero): 1 = no media, 2 = no traversal
-// (every ray "hits" primitive 0 of the first non-empty kind at t = 1), 4 = no scatter (fixed attenuation, bounce along the normal).
-template <bool STATS, int ABL>
-__global__ __launch_bounds__(RT_BLOCK) void k_bounce(RtSceneView sc, RtFrameDev fr, int bounce, uint32_t cap, const uint32_t* counts_in,
-                                                     uint32_t* counts_out, const rt_f4* ia, const rt_f4* ib, const rt_f4* ic,
-                                                     rt_f4* oa, rt_f4* ob, rt_f4* oc, rt_f4* contrib, unsigned long long* work) {
-    __shared__ int s_stack[RT_STACK_DEPTH * RT_BLOCK];
-    LdsStack stk; stk.base = s_stack + threadIdx.x;
+// Node records: the first n_cached nodes (the top levels, nodes are numbered breadth-first) come from LDS.
+struct CachedNodes {
+    const rt_f4* global; const rt_f4* lds; int32_t n_cached;
+    __device__ __forceinline__ void get(int32_t n, rt_f4 q[4]) const {
+        if (n < n_cached) {
+            const rt_f4* p = lds + 4 * n;
+            q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = p[3];
+        } else {
+            const rt_f4* p = global + 4 * (size_t)n;
+            q[0] = ld4(p); q[1] = ld4(p + 1); q[2] = ld4(p + 2); q[3] = ld4(p + 3);
+        }
+    }
+};
+
+// Stage 1 of a bounce: closest surface hit of every queued ray (lib.rs:63 without the media).
+// Persistent waves: a lane that has finished its ray waits until `refill_lanes` lanes of its wave are idle, then
+// the idle lanes take the next rays of the region through one wave-aggregated atomic on the region's cursor.  Rays
+// that need 100+ node visits therefore do not hold 63 finished lanes idle, which is what a ray-per-thread launch
+// costs on 64-wide waves.  Dynamic LDS: [n_cached nodes][stack_depth x RT_BLOCK ints].
+template <bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace(RtSceneView sc, uint32_t cap, const uint32_t* counts_in, uint32_t* cursors,
+                                                    const rt_f4* ia, const rt_f4* ib, rt_f4* hits, int n_cached, int stack_depth,
+                                                    int refill_lanes, unsigned long long* work) {
+    if (counts_in[blockIdx.y * RT_COUNT_STRIDE] == 0) return;
+    extern __shared__ __align__(16) unsigned char smem[];
+    rt_f4* s_nodes = reinterpret_cast<rt_f4*>(smem);
+    int* s_stack = reinterpret_cast<int*>(smem + (size_t)n_cached * 64);
+    for (int i = threadIdx.x; i < n_cached * 4; i += RT_BLOCK) s_nodes[i] = ld4(sc.nodes + i);
+    __syncthreads();
+    LdsStack stk; stk.base = s_stack + threadIdx.x; stk.depth = stack_depth;
+    CachedNodes nodes; nodes.global = sc.nodes; nodes.lds = s_nodes; nodes.n_cached = n_cached;
+
+    const uint32_t region = blockIdx.y;
+    const uint32_t n = counts_in[region * RT_COUNT_STRIDE];
+    uint32_t* cursor = cursors + region * RT_COUNT_STRIDE;
+    ia += (size_t)region * cap; ib += (size_t)region * cap; hits += (size_t)region * cap;
+
+    bool active = false, exhausted = false;
+    uint32_t slot = 0, src = RT_HIT_NONE;
+    v3 wo = mk3(0, 0, 0), wd = mk3(0, 0, 1);
+    float time = 0.0f;
+    RtTrav tv; tv.o = wo; tv.d = wd; tv.inv = wd; tv.inst = -1; tv.sp = 0; tv.cur = RT_EMPTY_STACK;
+    RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
+    RtCounters cnt = {0, 0, 0, 0, 0, 0};
+
+    for (;;) {
+        unsigned long long am = __ballot(active);
+        int n_idle = 64 - __popcll(am);
+        if (!exhausted && (n_idle >= refill_lanes || am == 0)) {
+            unsigned long long im = ~am;
+            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
+            uint32_t base = 0;
+            if (!active && rank == 0) base = atomicAdd(cursor, (uint32_t)n_idle);
+            base = __shfl(base, __ffsll((long long)im) - 1);
+            if (!active) {
+                uint32_t idx = base + rank;
+                if (idx < n) {
+                    rt_f4 a = ld4(ia + idx), b = ld4(ib + idx);
+                    wo = mk3(a.x, a.y, a.z); wd = mk3(b.x, b.y, b.z); time = a.w; src = (uint32_t)f2i(b.w);
+                    slot = idx; active = true;
+                    hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
+                    rt_trav_begin(sc, wo, wd, tv);
+                }
+            }
+            if (base + (uint32_t)n_idle >= n) exhausted = true;
+            am = __ballot(active);
+        }
+        if (am == 0) break;
+        if (active) {
+            while (rt_is_inner(tv.cur)) rt_node_step<STATS>(nodes, tv, RT_TMIN, hit, stk, &cnt);
+            if (tv.cur >= 0) {
+                if (tv.cur != RT_EMPTY_STACK) rt_sentinel_step(wo, wd, tv, stk);
+            } else {
+                do rt_leaf_step<STATS>(sc, wo, wd, time, RT_TMIN, src, tv, hit, stk, &cnt); while (tv.cur < 0);
+            }
+            if (tv.cur == RT_EMPTY_STACK) {
+                *reinterpret_cast<float4*>(hits + slot) = make_float4(hit.t, i2f((int)hit.code), i2f(hit.inst), 0.0f);
+                active = false;
+            }
+        }
+    }
+    if (STATS) {
+        atomicAdd(work + 0, (unsigned long long)cnt.nodes); atomicAdd(work + 1, (unsigned long long)cnt.spheres);
+        atomicAdd(work + 2, (unsigned long long)cnt.mspheres); atomicAdd(work + 3, (unsigned long long)cnt.rects);
+        atomicAdd(work + 4, (unsigned long long)cnt.instances); atomicAdd(work + 7, (unsigned long long)cnt.boxes);
+    }
+}
+
+// Stage 2 of a bounce: media (mediums.rs:39-87), hit record, emission and scatter (lib.rs:64-71) for every ray of the
+// input queue, and the append of the scattered ray to the output queue through one wave-aggregated atomic
+// (ranks from ballot + mbcnt).  STATS = true also counts shades per material kind into `work` (16 x u64).
+template <bool STATS>
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev fr, int bounce, uint32_t cap, const uint32_t* counts_in,
+                                                    uint32_t* counts_out, const rt_f4* ia, const rt_f4* ib, const rt_f4* ic,
+                                                    const rt_f4* hits, rt_f4* oa, rt_f4* ob, rt_f4* oc, rt_f4* contrib,
+                                                    unsigned long long* work) {
     const uint32_t n = counts_in[blockIdx.y * RT_COUNT_STRIDE];
     const uint32_t out_shard = (blockIdx.x + blockIdx.y) % RT_SHARDS;
     uint32_t* n_out_ptr = counts_out + out_shard * RT_COUNT_STRIDE;
-    ia += (size_t)blockIdx.y * cap; ib += (size_t)blockIdx.y * cap; ic += (size_t)blockIdx.y * cap;
+    ia += (size_t)blockIdx.y * cap; ib += (size_t)blockIdx.y * cap; ic += (size_t)blockIdx.y * cap; hits += (size_t)blockIdx.y * cap;
     oa += (size_t)out_shard * cap; ob += (size_t)out_shard * cap; oc += (size_t)out_shard * cap;
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
         uint32_t i = base + threadIdx.x;
@@ -91,27 +180,19 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(RtSceneView sc, RtFrameDev 
         rt_f4 na, nb, nc;
         na.x = na.y = na.z = na.w = nb.x = nb.y = nb.z = nb.w = nc.x = nc.y = nc.z = nc.w = 0.0f;
         if (i < n) {
-            rt_f4 a = ld4(ia + i), b = ld4(ib + i), c = ld4(ic + i);
+            rt_f4 a = ld4(ia + i), b = ld4(ib + i), c = ld4(ic + i), h = ld4(hits + i);
             v3 o = mk3(a.x, a.y, a.z), d = mk3(b.x, b.y, b.z), beta = mk3(c.x, c.y, c.z);
             float time = a.w;
-            uint32_t src = (uint32_t)f2i(b.w), pid = (uint32_t)f2i(c.w);
+            uint32_t pid = (uint32_t)f2i(c.w);
             uint32_t pixel, sample;
             rt_split_path(fr, pid, pixel, sample);
             sample += (uint32_t)fr.sample_base;
             uint32_t rnd[4];
             rt_philox(pixel, sample, (uint32_t)bounce, 0u, fr.key0, fr.key1, rnd);
 
-            RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
-            RtCounters cnt = {0, 0, 0, 0, 0, 0};
-            if (ABL & 2) { hit.t = 1.0f; hit.code = RT_HIT_CODE(sc.n_rects > 0 ? RT_KIND_RECT : RT_KIND_SPHERE, pid % 5u); }
-            else rt_closest_hit<STATS>(sc, o, d, time, RT_TMIN, src, stk, hit, &cnt);
-            if (!(ABL & 1) && sc.n_media > 0) rt_media_hits(sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, rnd, hit);
-            if (STATS) {
-                atomicAdd(work + 0, (unsigned long long)cnt.nodes); atomicAdd(work + 1, (unsigned long long)cnt.spheres);
-                atomicAdd(work + 2, (unsigned long long)cnt.mspheres); atomicAdd(work + 3, (unsigned long long)cnt.rects);
-                atomicAdd(work + 4, (unsigned long long)cnt.instances); atomicAdd(work + 5, (unsigned long long)sc.n_media);
-                if (hit.code == RT_HIT_NONE) atomicAdd(work + 6, 1ull);
-            }
+            RtHit hit; hit.t = h.x; hit.code = (uint32_t)f2i(h.y); hit.inst = f2i(h.z);
+            if (sc.n_media > 0) rt_media_hits(sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, rnd, hit);
+            if (STATS) { atomicAdd(work + 5, (unsigned long long)sc.n_media); if (hit.code == RT_HIT_NONE) atomicAdd(work + 6, 1ull); }
 
             v3 add = mk3(0, 0, 0);
             if (hit.code == RT_HIT_NONE) {
@@ -120,15 +201,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_bounce(RtSceneView sc, RtFrameDev 
                 RtSurface sf;
                 rt_surface(sc, o, d, time, hit, false, sf);
                 v3 atten, dir, emitted;
-                bool scattered;
-                if (ABL & 4) { atten = mk3(0.8f, 0.8f, 0.8f); dir = sf.n + mk3(rt_u24(rnd[0]), rt_u24(rnd[1]), rt_u24(rnd[2])); emitted = mk3(0, 0, 0); scattered = rnd[3] > 0x30000000u; }
-                else scattered = rt_scatter(sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), atten, dir, emitted);
+                bool scattered = rt_scatter(sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), atten, dir, emitted);
                 if (STATS) {
                     rt_f4 a0 = ld4(sc.materials + 2 * (size_t)sf.mat);
-                    int mtype = f2i(a0.x);
+                    int mtype = f2i(a0.x), mtex = f2i(a0.y);
                     atomicAdd(work + 8 + mtype, 1ull);                                     // shades per material kind
-                    if (mtype != RT_MAT_METAL && mtype != RT_MAT_DIELECTRIC) {            // texture kind behind the material
-                        int tt = f2i(ld4(sc.textures + 2 * (size_t)f2i(a0.y)).x);
+                    if (mtex >= 0 && mtype != RT_MAT_METAL && mtype != RT_MAT_DIELECTRIC) { // texture kind behind the material
+                        int tt = f2i(ld4(sc.textures + 2 * (size_t)mtex).x);
                         if (tt == RT_TEX_NOISE) atomicAdd(work + 13, 1ull); else if (tt == RT_TEX_CHECKER) atomicAdd(work + 14, 1ull);
                     }
                 }
@@ -184,7 +263,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const rt_f4* contrib, i
 __global__ __launch_bounds__(RT_BLOCK) void k_primary(RtSceneView sc, RtCameraDev cam, RtFrameDev fr, uint32_t sample, int32_t* ids,
                                                       float* ts, float* normals, int32_t* fronts, float* uvs) {
     __shared__ int s_stack[RT_STACK_DEPTH * RT_BLOCK];
-    LdsStack stk; stk.base = s_stack + threadIdx.x;
+    LdsStack stk; stk.base = s_stack + threadIdx.x; stk.depth = RT_STACK_DEPTH;
     uint32_t pixel = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (pixel >= (uint32_t)fr.n_pixels) return;
     v3 o, d; float time;
@@ -208,7 +287,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(RtSceneView sc, RtCameraDe
 __global__ __launch_bounds__(RT_BLOCK) void k_scatter_rays(RtSceneView sc, const float* rays, int n, uint32_t pixel0, uint32_t sample, int bounce,
                                                            uint32_t key0, uint32_t key1, float* out) {
     __shared__ int s_stack[RT_STACK_DEPTH * RT_BLOCK];
-    LdsStack stk; stk.base = s_stack + threadIdx.x;
+    LdsStack stk; stk.base = s_stack + threadIdx.x; stk.depth = RT_STACK_DEPTH;
     int i = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i >= n) return;
     const float* r = rays + 7 * (size_t)i;
@@ -241,10 +320,15 @@ struct RtScene {
     uint64_t device_bytes = 0;
     // render workspace (grow-only)
     size_t ws_paths = 0, ws_cap = 0;   // paths the workspace was sized for; slots per queue region
-    rt_f4 *qa[2] = {nullptr, nullptr}, *qb[2] = {nullptr, nullptr}, *qc[2] = {nullptr, nullptr}, *contrib = nullptr;
-    uint32_t* counts = nullptr;
+    rt_f4 *qa[2] = {nullptr, nullptr}, *qb[2] = {nullptr, nullptr}, *qc[2] = {nullptr, nullptr}, *contrib = nullptr, *hits = nullptr;
+    uint32_t* counts = nullptr;            // [bounce][region] queue sizes, then [bounce][region] trace cursors
+    int lds_nodes = 0, lds_bytes = 0;      // k_trace: nodes cached in LDS and its dynamic LDS size
     unsigned long long* work = nullptr;   // 16 work counters of the instrumented kernel
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> ev_trace;      // per-bounce event pairs around k_trace (RT_FLAG_TIME_TRACE)
+    int lds_stack = 1;                     // stack entries per ray in k_trace
+    int refill_lanes = 16;                 // idle lanes of a wave that trigger a refill in k_trace
+    int trace_blocks_per_cu = 4;           // resident k_trace blocks per CU (0 = as many as the LDS allows); more thrash the 32 KB L1
 };
 
 template <class T>
@@ -264,10 +348,12 @@ static int upload(RtScene* s, const std::vector<T>& v, const T** out) {
 static void free_workspace(RtScene* s) {
     for (int i = 0; i < 2; ++i) { if (s->qa[i]) (void)hipFree(s->qa[i]); if (s->qb[i]) (void)hipFree(s->qb[i]); if (s->qc[i]) (void)hipFree(s->qc[i]); s->qa[i] = s->qb[i] = s->qc[i] = nullptr; }
     if (s->contrib) (void)hipFree(s->contrib);
+    if (s->hits) (void)hipFree(s->hits);
+    s->hits = nullptr;
     s->contrib = nullptr; s->ws_paths = 0; s->ws_cap = 0;
 }
 static int ensure_workspace(RtScene* s, size_t n_paths) {
-    if (!s->counts) { HIP_TRY(hipMalloc((void**)&s->counts, (size_t)(RT_MAX_BOUNCES + 2) * RT_SHARDS * RT_COUNT_STRIDE * sizeof(uint32_t))); }
+    if (!s->counts) { HIP_TRY(hipMalloc((void**)&s->counts, (size_t)2 * (RT_MAX_BOUNCES + 2) * RT_SHARDS * RT_COUNT_STRIDE * sizeof(uint32_t))); }
     if (!s->work) { HIP_TRY(hipMalloc((void**)&s->work, 16 * sizeof(unsigned long long))); }
     if (!s->ev0) { HIP_TRY(hipEventCreate(&s->ev0)); HIP_TRY(hipEventCreate(&s->ev1)); }
     if (s->ws_paths >= n_paths) return RT_OK;
@@ -280,6 +366,7 @@ static int ensure_workspace(RtScene* s, size_t n_paths) {
         HIP_TRY(hipMalloc((void**)&s->qc[i], cap * RT_SHARDS * sizeof(rt_f4)));
     }
     HIP_TRY(hipMalloc((void**)&s->contrib, n_paths * sizeof(rt_f4)));
+    HIP_TRY(hipMalloc((void**)&s->hits, cap * RT_SHARDS * sizeof(rt_f4)));
     s->ws_paths = n_paths; s->ws_cap = cap;
     return RT_OK;
 }
@@ -356,7 +443,17 @@ int rt_scene_create(const RtBuilder* b, RtObj world, int device, RtScene** out) 
         if ((r = upload(s, f.textures, &v.textures))) return r;
         if ((r = upload(s, f.perlin_vec, &v.perlin_vec))) return r;
         if ((r = upload(s, f.perlin_perm, &v.perlin_perm))) return r;
+        if ((r = upload(s, f.boxes, &v.boxes))) return r;
         s->view = v;
+        // LDS plan of k_trace: the exact stack the BVH can need, the rest of a 32 KB block budget for the top nodes
+        const char* env = std::getenv("RT_LDS_BUDGET_KB");
+        int budget = (env ? std::max(4, std::min(64, std::atoi(env))) : 40) * 1024;
+        s->lds_stack = std::max(1, f.max_stack);
+        int stack_bytes = s->lds_stack * RT_BLOCK * (int)sizeof(int);
+        s->lds_nodes = std::max(0, std::min(v.n_nodes, (budget - stack_bytes) / 64));
+        s->lds_bytes = stack_bytes + s->lds_nodes * 64;
+        if (const char* e2 = std::getenv("RT_REFILL_LANES")) s->refill_lanes = std::max(1, std::min(64, std::atoi(e2)));
+        if (const char* e3 = std::getenv("RT_TRACE_BLOCKS_PER_CU")) s->trace_blocks_per_cu = std::max(0, std::min(8, std::atoi(e3)));
         return RT_OK;
     }();
     if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
@@ -373,12 +470,13 @@ void rt_scene_destroy(RtScene* s) {
     if (s->work) (void)hipFree(s->work);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    for (hipEvent_t e : s->ev_trace) (void)hipEventDestroy(e);
     delete s;
 }
 
 static void fill_info(const rt::FlatScene& f, RtSceneInfo* o) {
     RtSceneView v = f.view();
-    o->n_nodes = v.n_nodes; o->n_spheres = v.n_spheres; o->n_moving_spheres = v.n_mspheres; o->n_rects = v.n_rects;
+    o->n_nodes = v.n_nodes; o->n_spheres = v.n_spheres; o->n_moving_spheres = v.n_mspheres; o->n_rects = v.n_rects; o->n_boxes = v.n_boxes;
     o->n_instances = v.n_instances; o->n_media = v.n_media; o->n_materials = v.n_materials; o->n_textures = v.n_textures; o->n_perlin = v.n_perlin;
     o->tlas_depth = f.tlas_depth; o->blas_depth = f.blas_depth; o->max_stack = f.max_stack; o->n_objects = f.n_ids; o->device = -1;
     for (int i = 0; i < 6; ++i) o->world_box[i] = f.world_box[i];
@@ -408,7 +506,9 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     RtCameraDev cd; make_cam(cam, cd);
     RtFrameDev fr; make_frame(p, fr);
     const size_t n_pixels = (size_t)fr.n_pixels;
-    size_t target = p->paths_per_pass > 0 ? (size_t)p->paths_per_pass : ((size_t)1 << 23);
+    // Default pass: up to 2^26 paths in flight (7.5 GB of queues).  The late bounces of a pass are latency-bound
+    // (a few long rays per launch), so their fixed cost is amortised over as many paths as fit comfortably in HBM.
+    size_t target = p->paths_per_pass > 0 ? (size_t)p->paths_per_pass : ((size_t)1 << 26);
     int chunk_max = (int)std::max<size_t>(1, target / n_pixels);
     if ((size_t)chunk_max * n_pixels > 0xFFFFFFF0ull) chunk_max = (int)(0xFFFFFFF0ull / n_pixels);
     chunk_max = std::min(chunk_max, std::max(1, p->spp));
@@ -422,6 +522,14 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     const uint32_t cap = (uint32_t)s->ws_cap;
     float* sq = (p->flags & RT_FLAG_SUMSQ) ? d_accum_sq : nullptr;
     const bool instrumented = (p->flags & RT_FLAG_COUNTERS) != 0;
+    const bool time_trace = (p->flags & RT_FLAG_TIME_TRACE) != 0;
+    if (time_trace) {
+        while ((int)s->ev_trace.size() < 2 * p->max_depth) { hipEvent_t e = nullptr; HIP_TRY(hipEventCreate(&e)); s->ev_trace.push_back(e); }
+    }
+    // k_trace: persistent grid, as many blocks as stay resident (LDS-limited), split over the regions
+    const int lds_limit = std::max(1, std::min(8, (160 * 1024) / std::max(1, s->lds_bytes)));
+    const int blocks_per_cu = s->trace_blocks_per_cu > 0 ? std::min(s->trace_blocks_per_cu, lds_limit) : lds_limit;
+    dim3 tgrid((unsigned)std::max(1, (std::max(1, s->n_cu) * blocks_per_cu + RT_SHARDS - 1) / RT_SHARDS), RT_SHARDS);
     if (instrumented) HIP_TRY(hipMemsetAsync(s->work, 0, 16 * sizeof(unsigned long long), st));
 
     for (int done = 0; done < p->spp;) {
@@ -429,6 +537,7 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         uint32_t n_paths = (uint32_t)((size_t)chunk * n_pixels);
         fr.spp_chunk = chunk; fr.sample_base = p->sample_offset + done;
         HIP_TRY(hipMemsetAsync(s->counts, 0, counts_bytes, st));
+        HIP_TRY(hipMemsetAsync(s->counts + (size_t)(RT_MAX_BOUNCES + 2) * RT_SHARDS * RT_COUNT_STRIDE, 0, counts_bytes, st));
         HIP_TRY(hipMemsetAsync(s->contrib, 0, (size_t)n_paths * sizeof(rt_f4), st));
         int grid = (int)std::min<size_t>(((size_t)n_paths + RT_BLOCK - 1) / RT_BLOCK, (size_t)grid_cap);
         hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, cd, fr, n_paths, cap, s->counts + RT_SHARDS * RT_COUNT_STRIDE, s->qa[0], s->qb[0], s->qc[0]);
@@ -440,21 +549,23 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         HIP_TRY(hipEventRecord(s->ev0, st));
         for (int b = 1; b <= p->max_depth; ++b) {
             int in = (b - 1) & 1, outq = b & 1;
-#define RT_LAUNCH_BOUNCE(STATS_, ABL_)                                                                                         \
-    hipLaunchKernelGGL((k_bounce<STATS_, ABL_>), bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, s->counts + (size_t)b * RT_SHARDS * RT_COUNT_STRIDE, \
-                       s->counts + (size_t)(b + 1) * RT_SHARDS * RT_COUNT_STRIDE,                                                                     \
-                       s->qa[in], s->qb[in], s->qc[in], s->qa[outq], s->qb[outq], s->qc[outq], s->contrib, s->work)
-            switch (instrumented ? -1 : ((p->flags >> 8) & 7)) {
-                case -1: RT_LAUNCH_BOUNCE(true, 0); break;
-                case 1: RT_LAUNCH_BOUNCE(false, 1); break;
-                case 2: RT_LAUNCH_BOUNCE(false, 2); break;
-                case 3: RT_LAUNCH_BOUNCE(false, 3); break;
-                case 4: RT_LAUNCH_BOUNCE(false, 4); break;
-                case 5: RT_LAUNCH_BOUNCE(false, 5); break;
-                case 7: RT_LAUNCH_BOUNCE(false, 7); break;
-                default: RT_LAUNCH_BOUNCE(false, 0); break;
-            }
-#undef RT_LAUNCH_BOUNCE
+            const uint32_t* cin = s->counts + (size_t)b * RT_SHARDS * RT_COUNT_STRIDE;
+            uint32_t* cout = s->counts + (size_t)(b + 1) * RT_SHARDS * RT_COUNT_STRIDE;
+            uint32_t* cursors = s->counts + (size_t)(RT_MAX_BOUNCES + 2 + b) * RT_SHARDS * RT_COUNT_STRIDE;
+            if (time_trace) HIP_TRY(hipEventRecord(s->ev_trace[2 * (b - 1)], st));
+            if (instrumented)
+                hipLaunchKernelGGL(k_trace<true>, tgrid, dim3(RT_BLOCK), (size_t)s->lds_bytes, st, s->view, cap, cin, cursors, s->qa[in], s->qb[in],
+                                   s->hits, s->lds_nodes, s->lds_stack, s->refill_lanes, s->work);
+            else
+                hipLaunchKernelGGL(k_trace<false>, tgrid, dim3(RT_BLOCK), (size_t)s->lds_bytes, st, s->view, cap, cin, cursors, s->qa[in], s->qb[in],
+                                   s->hits, s->lds_nodes, s->lds_stack, s->refill_lanes, s->work);
+            if (time_trace) HIP_TRY(hipEventRecord(s->ev_trace[2 * (b - 1) + 1], st));
+            if (instrumented)
+                hipLaunchKernelGGL(k_shade<true>, bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, cin, cout, s->qa[in], s->qb[in], s->qc[in], s->hits,
+                                   s->qa[outq], s->qb[outq], s->qc[outq], s->contrib, s->work);
+            else
+                hipLaunchKernelGGL(k_shade<false>, bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, cin, cout, s->qa[in], s->qb[in], s->qc[in], s->hits,
+                                   s->qa[outq], s->qb[outq], s->qc[outq], s->contrib, s->work);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(s->ev1, st));
@@ -466,6 +577,14 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
         local.kernel_ms_extend += ms; local.extend_launches += (uint64_t)p->max_depth; local.passes++;
+        if (time_trace) {
+            for (int b = 0; b < p->max_depth; ++b) {
+                float tms = 0.0f;
+                HIP_TRY(hipEventElapsedTime(&tms, s->ev_trace[2 * b], s->ev_trace[2 * b + 1]));
+                local.kernel_ms_trace += tms;
+            }
+            local.trace_launches += (uint64_t)p->max_depth;
+        }
         for (int b = 1; b <= p->max_depth; ++b) {
             uint64_t nb = 0;
             for (int sh = 0; sh < RT_SHARDS; ++sh) nb += h_counts[((size_t)b * RT_SHARDS + sh) * RT_COUNT_STRIDE];

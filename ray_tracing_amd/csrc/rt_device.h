@@ -16,8 +16,10 @@
 
 #if defined(__HIPCC__)
 #define RT_HD __host__ __device__ __forceinline__
+#define RT_HDM __host__ __device__ __forceinline__   /* member functions */
 #else
 #define RT_HD static inline
+#define RT_HDM inline
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -161,38 +163,26 @@ RT_HD void rt_camera_ray(const RtCameraDev& cam, const RtFrameDev& fr, uint32_t 
 // ------------------------------------------------------------------ primitive tests
 // All return the accepted t, or NaN for "no hit in [tmin, tmax]".
 //
-// Sphere (objects.rs:205-239): nearer root if in range, else the farther one.  fp32 cannot afford
-// the reference's half_b^2 - a*c (catastrophic for r = 1000 / 5000), so the discriminant comes from
-// the distance between centre and ray line, and the two roots from q = b' + sign(b') sqrt(a*delta)
+// Sphere (objects.rs:205-239): nearer root if in range, else the farther one.  The two roots come from
+// q = b' + sign(b') sqrt(disc) as q/a and c/q, which avoids the cancellation of -b' +- sqrt(disc)
 // (Haines et al., "Precision improvements for ray/sphere intersection", Ray Tracing Gems ch. 7).
 // `self` = the ray starts on this very sphere: the roots are then exactly {0, 2b'/a}; the zero
 // root is what the reference discards through t_min = 0.001.
 RT_HD bool rt_sphere_roots(v3 c, float r, v3 o, v3 d, float& tn, float& tf) {
-    v3 f = o - c;
-    float a = dot3(d, d), ia = rt_rcp(a);
-    float bp = -dot3(f, d);
-    float cc = fmaf(-r, r, dot3(f, f));
-    float disc;
-    if (fabsf(cc) < 0.125f * r * r) {
-        // Origin within a few percent of the radius from the surface (the r = 1000 ground spheres
-        // seen from a camera 3 units above them): f.f - r^2 and the discriminant cancel in fp32.
-        // Redo the cancelling terms of objects.rs:206-210 in f64 (full-rate FMA on gfx950).
-        double fx = (double)o.x - (double)c.x, fy = (double)o.y - (double)c.y, fz = (double)o.z - (double)c.z;
-        double dx = d.x, dy = d.y, dz = d.z, rr = r;
-        double A = dx * dx + dy * dy + dz * dz;
-        double B = -(fx * dx + fy * dy + fz * dz);
-        double Cc = fx * fx + fy * fy + fz * fz - rr * rr;
-        double D = B * B - A * Cc;
-        if (!(D >= 0.0)) return false;
-        bp = (float)B; cc = (float)Cc; disc = (float)D;
-    } else {
-        v3 l = fma3(bp * ia, d, f);
-        float delta = fmaf(r, r, -dot3(l, l));
-        if (!(delta >= 0.0f)) return false;
-        disc = a * delta;
-    }
-    float q = bp + copysignf(rt_sqrt(disc), bp);
-    float ta = q * ia, tb = cc * rt_rcp(q);
+    // The cancelling terms of objects.rs:206-210 (oc = o - c, c = |oc|^2 - r^2, discriminant) are formed in f64:
+    // in fp32 they lose all digits for the r = 1000 ground spheres seen from 3 units above, and for every
+    // grazing hit.  gfx950 issues f64 FMAs at the fp32 FMA rate, and doing it always (instead of only when
+    // fp32 would fail) keeps the 64 lanes of a wave on one code path.
+    double fx = (double)o.x - (double)c.x, fy = (double)o.y - (double)c.y, fz = (double)o.z - (double)c.z;
+    double dx = d.x, dy = d.y, dz = d.z, rr = r;
+    double A = dx * dx + dy * dy + dz * dz;
+    double B = -(fx * dx + fy * dy + fz * dz);
+    double Cc = fx * fx + fy * fy + fz * fz - rr * rr;
+    double D = B * B - A * Cc;
+    if (!(D >= 0.0)) return false;
+    float a = (float)A, bp = (float)B, cc = (float)Cc;
+    float q = bp + copysignf(rt_sqrt((float)D), bp);
+    float ta = q * rt_rcp(a), tb = cc * rt_rcp(q);
     tn = fminf(ta, tb); tf = fmaxf(ta, tb);
     return true;
 }
@@ -223,6 +213,32 @@ RT_HD float rt_hit_rect(rt_f4 r0, float k, int type, v3 o, v3 d, float tmin, flo
     return t;
 }
 
+// BoxObj (objects.rs:433-512) as one primitive.  The reference scans the six rectangles and keeps the closest hit
+// in range; for a convex box those hits are the entry and the exit face of a slab test, and each slab distance
+// (k - o[a]) / d[a] is the very expression of the rectangle test (objects.rs:390).  Returns the accepted t (NaN:
+// none) and the side index in `face` (0..5 = z max, z min, y max, y min, x max, x min).  `skip` = side the ray
+// starts on (-1: none), which a ray can never re-hit.
+RT_HD bool rt_box_slabs(rt_f4 b0, rt_f4 b1, v3 o, v3 d, float& t_in, float& t_out, int& f_in, int& f_out) {
+    float ix = rt_rcp(d.x), iy = rt_rcp(d.y), iz = rt_rcp(d.z);
+    float x0 = (b0.x - o.x) * ix, x1 = (b1.x - o.x) * ix;
+    float y0 = (b0.y - o.y) * iy, y1 = (b1.y - o.y) * iy;
+    float z0 = (b0.z - o.z) * iz, z1 = (b1.z - o.z) * iz;
+    float ex = fminf(x0, x1), ey = fminf(y0, y1), ez = fminf(z0, z1);
+    float lx = fmaxf(x0, x1), ly = fmaxf(y0, y1), lz = fmaxf(z0, z1);
+    t_in = fmaxf(fmaxf(ex, ey), ez); t_out = fminf(fminf(lx, ly), lz);
+    // side through which the ray enters: the axis whose near plane is farthest; its min side when d > 0
+    f_in = t_in == ez ? (d.z > 0.0f ? 1 : 0) : (t_in == ey ? (d.y > 0.0f ? 3 : 2) : (d.x > 0.0f ? 5 : 4));
+    f_out = t_out == lz ? (d.z > 0.0f ? 0 : 1) : (t_out == ly ? (d.y > 0.0f ? 2 : 3) : (d.x > 0.0f ? 4 : 5));
+    return t_in <= t_out;
+}
+RT_HD float rt_hit_box(rt_f4 b0, rt_f4 b1, v3 o, v3 d, float tmin, float tmax, int skip, int& face) {
+    float t_in, t_out; int f_in, f_out;
+    if (!rt_box_slabs(b0, b1, o, d, t_in, t_out, f_in, f_out)) return rt_nan();
+    if (t_in >= tmin && t_in <= tmax && f_in != skip) { face = f_in; return t_in; }
+    if (t_out >= tmin && t_out <= tmax && f_out != skip) { face = f_out; return t_out; }
+    return rt_nan();
+}
+
 RT_HD v3 rt_msphere_center(rt_f4 m0, rt_f4 m1, rt_f4 m2, float time) {  // objects.rs:285-289
     float s = (time - m1.w) * m2.x;
     return mk3(fmaf(s, m1.x, m0.x), fmaf(s, m1.y, m0.y), fmaf(s, m1.z, m0.z));
@@ -251,7 +267,7 @@ RT_HD v3 rt_to_object_dir(rt_f4 i0, v3 d) {
 struct RtHit { float t; uint32_t code; int32_t inst; };
 
 // Work counters of an instrumented build (STATS = true); the normal kernels compile them away.
-struct RtCounters { uint32_t nodes, spheres, mspheres, rects, instances, media; };
+struct RtCounters { uint32_t nodes, spheres, mspheres, rects, instances, boxes; };
 
 // ------------------------------------------------------------------ closest surface hit
 // Stack-based traversal of the two-level BVH; equivalent to bvh.rs:159-187 + objects.rs:67-78
@@ -259,80 +275,121 @@ struct RtCounters { uint32_t nodes, spheres, mspheres, rects, instances, media; 
 // code of the surface the ray starts on (RT_HIT_NONE for camera rays and medium scatters): a
 // planar primitive can never be re-hit from itself and a sphere only through its far root, which
 // replaces the reference's reliance on f64 round-off staying below t_min.
-// On entry hit.t = tmax, hit.code = RT_HIT_NONE.  Stack: set(i, v) / get(i) on an int array.
+//
+// The traversal is written as three steps on an explicit state so that the plain per-ray loop below and the
+// persistent kernel (which refills finished lanes with new rays between steps) share them.
+//   Stack : set(i, v) / get(i) on an int array of cap() entries.      Nodes : get(node, q[4]) fetches the 64-byte node record.
+struct RtTrav { v3 o, d, inv; int32_t inst, sp, cur; };
+
+struct RtGlobalNodes {
+    const rt_f4* nodes;
+    RT_HDM void get(int32_t n, rt_f4 q[4]) const {
+        const rt_f4* p = nodes + 4 * (size_t)n;
+        q[0] = ld4(p); q[1] = ld4(p + 1); q[2] = ld4(p + 2); q[3] = ld4(p + 3);
+    }
+};
+
+RT_HD bool rt_is_inner(int32_t cur) { return (uint32_t)cur < (uint32_t)RT_SENTINEL; }
+
+RT_HD void rt_trav_begin(const RtSceneView& sc, v3 wo, v3 wd, RtTrav& tv) {
+    tv.o = wo; tv.d = wd; tv.inv = mk3(rt_rcp(wd.x), rt_rcp(wd.y), rt_rcp(wd.z));
+    tv.inst = -1; tv.sp = 0; tv.cur = sc.root < 0 ? RT_EMPTY_STACK : sc.root;
+}
+template <class Stack>
+RT_HD int32_t rt_pop(RtTrav& tv, Stack& stk) { return tv.sp > 0 ? stk.get(--tv.sp) : RT_EMPTY_STACK; }
+
+// tv.cur is an inner node: test both child boxes, descend into the nearer hit child, push the farther one.
+template <bool STATS, class Nodes, class Stack>
+RT_HD void rt_node_step(const Nodes& nodes, RtTrav& tv, float tmin, const RtHit& hit, Stack& stk, RtCounters* wc) {
+    rt_f4 q[4];
+    nodes.get(tv.cur, q);
+    if (STATS) wc->nodes++;
+    float tl = rt_slab(q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, tv.o, tv.inv, tmin, hit.t);
+    float tr = rt_slab(q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, tv.o, tv.inv, tmin, hit.t);
+    int32_t cl = f2i(q[3].x), cr = f2i(q[3].y);
+    bool hl = tl < rt_inf(), hr = tr < rt_inf();
+    if (hl && hr) {
+        bool left_first = tl <= tr;
+        if (tv.sp < stk.cap()) stk.set(tv.sp++, left_first ? cr : cl);
+        tv.cur = left_first ? cl : cr;
+    } else if (hl) tv.cur = cl;
+    else if (hr) tv.cur = cr;
+    else tv.cur = rt_pop(tv, stk);
+}
+
+// tv.cur is the sentinel pushed when an instance was entered: back to the world-space ray.
+template <class Stack>
+RT_HD void rt_sentinel_step(v3 wo, v3 wd, RtTrav& tv, Stack& stk) {
+    tv.o = wo; tv.d = wd; tv.inv = mk3(rt_rcp(wd.x), rt_rcp(wd.y), rt_rcp(wd.z)); tv.inst = -1;
+    tv.cur = rt_pop(tv, stk);
+}
+
+// tv.cur is a leaf code (< 0): enter the instance, or intersect the leaf's primitives; then pop.
+template <bool STATS, class Stack>
+RT_HD void rt_leaf_step(const RtSceneView& sc, v3 wo, v3 wd, float time, float tmin, uint32_t src, RtTrav& tv, RtHit& hit,
+                        Stack& stk, RtCounters* wc) {
+    uint32_t x = ~(uint32_t)tv.cur;
+    if (x & RT_LEAF_INSTANCE_BIT) {
+        int32_t ii = (int32_t)(x & 0x3FFFFFFFu);
+        rt_f4 i0 = ld4(sc.instances + 2 * (size_t)ii), i1 = ld4(sc.instances + 2 * (size_t)ii + 1);
+        if (tv.sp < stk.cap()) stk.set(tv.sp++, RT_SENTINEL);
+        tv.inst = ii;
+        if (STATS) wc->instances++;
+        tv.o = rt_to_object_point(i0, i1, wo); tv.d = rt_to_object_dir(i0, wd);
+        tv.inv = mk3(rt_rcp(tv.d.x), rt_rcp(tv.d.y), rt_rcp(tv.d.z));
+        tv.cur = f2i(i1.y);
+        return;
+    }
+    uint32_t kind = (x >> 28) & 3u, cnt = ((x >> 26) & 3u) + 1u, first = x & 0x03FFFFFFu;
+    for (uint32_t k = 0; k < cnt; ++k) {
+        uint32_t idx = first + k, code = RT_HIT_CODE(kind, idx);
+        float t;
+        if (kind == RT_KIND_BOX) {
+            if (STATS) wc->boxes++;
+            rt_f4 b0 = ld4(sc.boxes + 2 * (size_t)idx), b1 = ld4(sc.boxes + 2 * (size_t)idx + 1);
+            int skip = (src >> 3) == (RT_HIT_CODE(RT_KIND_BOX, idx << 3) >> 3) ? (int)(src & 7u) : -1, face = 0;
+            t = rt_hit_box(b0, b1, tv.o, tv.d, tmin, hit.t, skip, face);
+            code = RT_HIT_CODE(RT_KIND_BOX, (idx << 3) | (uint32_t)face);
+        } else if (kind == RT_KIND_RECT) {
+            if (STATS) wc->rects++;
+            if (code == src) continue;
+            rt_f4 r0 = ld4(sc.rects + 2 * (size_t)idx), r1 = ld4(sc.rects + 2 * (size_t)idx + 1);
+            t = rt_hit_rect(r0, r1.x, f2i(r1.y), tv.o, tv.d, tmin, hit.t);
+        } else {  // sphere or moving sphere: one intersection path, the centre is the only difference
+            v3 c; float r;
+            if (kind == RT_KIND_SPHERE) {
+                rt_f4 sp = ld4(sc.spheres + idx);
+                c = mk3(sp.x, sp.y, sp.z); r = sp.w;
+                if (STATS) wc->spheres++;
+            } else {
+                const rt_f4* m = sc.mspheres + 3 * (size_t)idx;
+                rt_f4 m0 = ld4(m), m1 = ld4(m + 1), m2 = ld4(m + 2);
+                c = rt_msphere_center(m0, m1, m2, time); r = m0.w;
+                if (STATS) wc->mspheres++;
+            }
+            t = rt_hit_sphere(c, r, tv.o, tv.d, tmin, hit.t, code == src);
+        }
+        if (t < hit.t) { hit.t = t; hit.code = code; hit.inst = tv.inst; }  // false for NaN
+    }
+    tv.cur = rt_pop(tv, stk);
+}
+
+// Whole traversal of one ray.  On entry hit.t = tmax, hit.code = RT_HIT_NONE.  "while-while" organisation: the
+// lane first descends inner nodes until it holds a leaf, then works on leaves, so that on a 64-wide wave the
+// box-test code and the primitive code are not issued in turn for every step of every lane.
 template <bool STATS, class Stack>
 RT_HD void rt_closest_hit(const RtSceneView& sc, v3 wo, v3 wd, float time, float tmin, uint32_t src, Stack& stk, RtHit& hit,
                           RtCounters* wc) {
-    if (sc.root < 0) return;
-    v3 o = wo, d = wd;
-    v3 inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
-    int32_t inst = -1, sp = 0, cur = sc.root;
-    // "while-while" organisation: every lane first descends inner nodes until it holds a leaf, then the wave
-    // works on leaves together.  On a 64-wide wave this keeps the box-test code and the primitive code from
-    // being issued in turn for every step of every lane.
-    for (;;) {
-        while ((uint32_t)cur < (uint32_t)RT_SENTINEL) {  // inner node
-            const rt_f4* n = sc.nodes + 4 * (size_t)cur;
-            rt_f4 q0 = ld4(n), q1 = ld4(n + 1), q2 = ld4(n + 2), q3 = ld4(n + 3);
-            if (STATS) wc->nodes++;
-            float tl = rt_slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tmin, hit.t);
-            float tr = rt_slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tmin, hit.t);
-            int32_t cl = f2i(q3.x), cr = f2i(q3.y);
-            bool hl = tl < rt_inf(), hr = tr < rt_inf();
-            if (hl && hr) {
-                bool left_first = tl <= tr;
-                if (sp < RT_STACK_DEPTH) stk.set(sp++, left_first ? cr : cl);
-                cur = left_first ? cl : cr;
-            } else if (hl) cur = cl;
-            else if (hr) cur = cr;
-            else cur = sp > 0 ? stk.get(--sp) : RT_EMPTY_STACK;
-        }
-        if (cur >= 0) {
-            if (cur == RT_EMPTY_STACK) break;
-            o = wo; d = wd; inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z)); inst = -1;  // sentinel: left the instance
-            cur = sp > 0 ? stk.get(--sp) : RT_EMPTY_STACK;
+    RtTrav tv;
+    rt_trav_begin(sc, wo, wd, tv);
+    RtGlobalNodes nodes; nodes.nodes = sc.nodes;
+    while (tv.cur != RT_EMPTY_STACK) {
+        while (rt_is_inner(tv.cur)) rt_node_step<STATS>(nodes, tv, tmin, hit, stk, wc);
+        if (tv.cur >= 0) {
+            if (tv.cur != RT_EMPTY_STACK) rt_sentinel_step(wo, wd, tv, stk);
             continue;
         }
-        do {  // leaf
-            uint32_t x = ~(uint32_t)cur;
-            if (x & RT_LEAF_INSTANCE_BIT) {
-                int32_t ii = (int32_t)(x & 0x3FFFFFFFu);
-                rt_f4 i0 = ld4(sc.instances + 2 * (size_t)ii), i1 = ld4(sc.instances + 2 * (size_t)ii + 1);
-                if (sp < RT_STACK_DEPTH) stk.set(sp++, RT_SENTINEL);
-                inst = ii;
-                if (STATS) wc->instances++;
-                o = rt_to_object_point(i0, i1, wo); d = rt_to_object_dir(i0, wd);
-                inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
-                cur = f2i(i1.y);
-                break;
-            }
-            uint32_t kind = (x >> 28) & 3u, cnt = ((x >> 26) & 3u) + 1u, first = x & 0x03FFFFFFu;
-            for (uint32_t k = 0; k < cnt; ++k) {
-                uint32_t idx = first + k, code = RT_HIT_CODE(kind, idx);
-                float t;
-                if (kind == RT_KIND_RECT) {
-                    if (STATS) wc->rects++;
-                    if (code == src) continue;
-                    rt_f4 r0 = ld4(sc.rects + 2 * (size_t)idx), r1 = ld4(sc.rects + 2 * (size_t)idx + 1);
-                    t = rt_hit_rect(r0, r1.x, f2i(r1.y), o, d, tmin, hit.t);
-                } else {  // sphere or moving sphere: one intersection path, the centre is the only difference
-                    v3 c; float r;
-                    if (kind == RT_KIND_SPHERE) {
-                        rt_f4 s = ld4(sc.spheres + idx);
-                        c = mk3(s.x, s.y, s.z); r = s.w;
-                        if (STATS) wc->spheres++;
-                    } else {
-                        const rt_f4* m = sc.mspheres + 3 * (size_t)idx;
-                        rt_f4 m0 = ld4(m), m1 = ld4(m + 1), m2 = ld4(m + 2);
-                        c = rt_msphere_center(m0, m1, m2, time); r = m0.w;
-                        if (STATS) wc->mspheres++;
-                    }
-                    t = rt_hit_sphere(c, r, o, d, tmin, hit.t, code == src);
-                }
-                if (t < hit.t) { hit.t = t; hit.code = code; hit.inst = inst; }  // false for NaN
-            }
-            cur = sp > 0 ? stk.get(--sp) : RT_EMPTY_STACK;
-        } while (cur < 0);
+        do rt_leaf_step<STATS>(sc, wo, wd, time, tmin, src, tv, hit, stk, wc); while (tv.cur < 0);
     }
 }
 
@@ -341,7 +398,7 @@ RT_HD void rt_closest_hit(const RtSceneView& sc, v3 wo, v3 wd, float time, float
 // boundary data comes in through scalar loads.
 //
 // Closest hit of the boundary's primitives inside [tmin, tmax] (linear scan = objects.rs:67-78).
-RT_HD float rt_boundary_hit(const RtSceneView& sc, rt_f4 m2, rt_f4 m3, v3 o, v3 d, float time, float tmin, float tmax) {
+RT_HD float rt_boundary_hit(const RtSceneView& sc, rt_f4 m2, rt_f4 m3, rt_f4 m4, v3 o, v3 d, float time, float tmin, float tmax) {
     float best = tmax; bool any = false;
     int s0 = rt_uniform(f2i(m2.y)), sn = rt_uniform(f2i(m2.z)), q0 = rt_uniform(f2i(m2.w)), qn = rt_uniform(f2i(m3.x));
     int r0 = rt_uniform(f2i(m3.y)), rn = rt_uniform(f2i(m3.z));
@@ -361,13 +418,20 @@ RT_HD float rt_boundary_hit(const RtSceneView& sc, rt_f4 m2, rt_f4 m3, v3 o, v3 
         float t = rt_hit_rect(a, b.x, f2i(b.y), o, d, tmin, best);
         if (t == t) { best = t; any = true; }
     }
+    int x0 = rt_uniform(f2i(m4.x)), xn = rt_uniform(f2i(m4.y));
+    for (int i = 0; i < xn; ++i) {
+        rt_f4 a = ld4(sc.boxes + 2 * (size_t)(x0 + i)), b = ld4(sc.boxes + 2 * (size_t)(x0 + i) + 1);
+        int face;
+        float t = rt_hit_box(a, b, o, d, tmin, best, -1, face);
+        if (t == t) { best = t; any = true; }
+    }
     return any ? best : rt_nan();
 }
 
 // The two smallest boundary crossings of the whole ray line, a <= b (+inf when absent), in one scan.  mediums.rs:46-47
 // asks for try_hit(-inf, inf) and then try_hit(t1 + 0.0001, inf): the first is the smallest crossing and the second
 // the smallest crossing that is >= t1 + 0.0001, which is b unless two crossings coincide (ray through an edge).
-RT_HD void rt_boundary_pair(const RtSceneView& sc, rt_f4 m2, rt_f4 m3, v3 o, v3 d, float time, float& a, float& b) {
+RT_HD void rt_boundary_pair(const RtSceneView& sc, rt_f4 m2, rt_f4 m3, rt_f4 m4, v3 o, v3 d, float time, float& a, float& b) {
     a = rt_inf(); b = rt_inf();
     int s0 = rt_uniform(f2i(m2.y)), sn = rt_uniform(f2i(m2.z)), q0 = rt_uniform(f2i(m2.w)), qn = rt_uniform(f2i(m3.x));
     int r0 = rt_uniform(f2i(m3.y)), rn = rt_uniform(f2i(m3.z));
@@ -388,6 +452,12 @@ RT_HD void rt_boundary_pair(const RtSceneView& sc, rt_f4 m2, rt_f4 m3, v3 o, v3 
         float t = rt_hit_rect(ra, rb.x, f2i(rb.y), o, d, -rt_inf(), rt_inf());
         if (t == t) RT_INSERT(t);
     }
+    int x0 = rt_uniform(f2i(m4.x)), xn = rt_uniform(f2i(m4.y));
+    for (int i = 0; i < xn; ++i) {  // a box is crossed at its entry and its exit side
+        rt_f4 ba = ld4(sc.boxes + 2 * (size_t)(x0 + i)), bb = ld4(sc.boxes + 2 * (size_t)(x0 + i) + 1);
+        float t_in, t_out; int f_in, f_out;
+        if (rt_box_slabs(ba, bb, o, d, t_in, t_out, f_in, f_out)) { RT_INSERT(t_in); RT_INSERT(t_out); }
+    }
 #undef RT_INSERT
 }
 
@@ -397,16 +467,20 @@ RT_HD void rt_boundary_pair(const RtSceneView& sc, rt_f4 m2, rt_f4 m3, v3 o, v3 
 // rnd0 = Philox block 0 of this bounce (its lanes 2, 3 are the draws of media 0, 1).
 RT_HD void rt_media_hits(const RtSceneView& sc, v3 wo, v3 wd, float time, float tmin, uint32_t pixel, uint32_t sample,
                          uint32_t bounce, uint32_t key0, uint32_t key1, const uint32_t rnd0[4], RtHit& hit) {
-    uint32_t rnd[4] = {rnd0[0], rnd0[1], rnd0[2], rnd0[3]};
+    uint32_t r0 = rnd0[0], r1 = rnd0[1], r2 = rnd0[2], r3 = rnd0[3];  // scalars: an indexed array would live in scratch
     float len = rt_sqrt(dot3(wd, wd));
     v3 winv = mk3(rt_rcp(wd.x), rt_rcp(wd.y), rt_rcp(wd.z));
     for (int m = 0; m < sc.n_media; ++m) {
         int k = m + 2;
-        if (k >= 4 && (k & 3) == 0) rt_philox(pixel, sample, bounce, (uint32_t)(k >> 2), key0, key1, rnd);
-        const rt_f4* md = sc.media + 4 * (size_t)m;
+        if (k >= 4 && (k & 3) == 0) {
+            uint32_t nr[4];
+            rt_philox(pixel, sample, bounce, (uint32_t)(k >> 2), key0, key1, nr);
+            r0 = nr[0]; r1 = nr[1]; r2 = nr[2]; r3 = nr[3];
+        }
+        const rt_f4* md = sc.media + RT_MEDIUM_F4 * (size_t)m;
         rt_f4 m0 = ld4(md), m1 = ld4(md + 1);
         if (!(rt_slab(m0.x, m0.y, m0.z, m1.x, m1.y, m1.z, wo, winv, tmin, hit.t) < rt_inf())) continue;
-        rt_f4 m2 = ld4(md + 2), m3 = ld4(md + 3);
+        rt_f4 m2 = ld4(md + 2), m3 = ld4(md + 3), m4 = ld4(md + 4);
         v3 o = wo, d = wd;
         int ii = rt_uniform(f2i(m2.x));
         if (ii >= 0) {
@@ -414,19 +488,21 @@ RT_HD void rt_media_hits(const RtSceneView& sc, v3 wo, v3 wd, float time, float 
             o = rt_to_object_point(i0, i1, wo); d = rt_to_object_dir(i0, wd);
         }
         float t1, t2;
-        rt_boundary_pair(sc, m2, m3, o, d, time, t1, t2);                           // mediums.rs:46-47
+        rt_boundary_pair(sc, m2, m3, m4, o, d, time, t1, t2);                           // mediums.rs:46-47
         if (!(t1 < rt_inf())) continue;
         // The re-query offset 0.0001 vanishes in fp32 once |t1| exceeds ~1000 (the r = 5000 fog), so it is widened
         // to a few ulps of t1 when that is larger.
         float t_next = t1 + fmaxf(0.0001f, 1e-6f * fabsf(t1));
-        if (t2 < t_next) t2 = rt_boundary_hit(sc, m2, m3, o, d, time, t_next, rt_inf());
+        if (t2 < t_next) t2 = rt_boundary_hit(sc, m2, m3, m4, o, d, time, t_next, rt_inf());
         if (!(t2 < rt_inf())) continue;                                             // also false for NaN (no second crossing)
         if (t1 < tmin) t1 = tmin;
         if (t2 > hit.t) t2 = hit.t;
         if (t1 >= t2) continue;
         if (t1 < 0.0f) t1 = 0.0f;
         float inside = (t2 - t1) * len;
-        float hit_dist = m0.w * rt_log10(rt_u24(rnd[k & 3]));                       // mediums.rs:64 (log base 10)
+        int lane4 = k & 3;
+        uint32_t draw = lane4 == 0 ? r0 : (lane4 == 1 ? r1 : (lane4 == 2 ? r2 : r3));
+        float hit_dist = m0.w * rt_log10(rt_u24(draw));                             // mediums.rs:64 (log base 10)
         if (hit_dist > inside) continue;
         float t = t1 + hit_dist * rt_rcp(len);
         if (t < hit.t) { hit.t = t; hit.code = RT_HIT_CODE(RT_KIND_MEDIUM, (uint32_t)m); hit.inst = -1; }
@@ -446,7 +522,7 @@ RT_HD void rt_surface(const RtSceneView& sc, v3 wo, v3 wd, float time, const RtH
     uint32_t kind = RT_HIT_KIND(h.code), idx = RT_HIT_INDEX(h.code);
     s.u = 0.0f; s.v = 0.0f;
     if (kind == RT_KIND_MEDIUM) {  // mediums.rs:69-80
-        const rt_f4* md = sc.media + 4 * (size_t)idx;
+        const rt_f4* md = sc.media + RT_MEDIUM_F4 * (size_t)idx;
         s.p = fma3(h.t, wd, wo);
         s.front = wd.x < 0.0f;
         s.n = mk3(s.front ? 1.0f : -1.0f, 0.0f, 0.0f);
@@ -472,6 +548,16 @@ RT_HD void rt_surface(const RtSceneView& sc, v3 wo, v3 wd, float time, const RtH
         on = normalize3(rt_rcp(m0.w) * (p - rt_msphere_center(m0, m1, m2, time)));  // objects.rs:313
         meta = sc.msphere_meta[idx];
         if (want_uv) rt_sphere_uv(on, &s.u, &s.v);
+    } else if (kind == RT_KIND_BOX) {  // side `idx & 7` of box `idx >> 3`, as the rectangle objects.rs:445-500 builds
+        rt_f4 b0 = ld4(sc.boxes + 2 * (size_t)(idx >> 3)), b1 = ld4(sc.boxes + 2 * (size_t)(idx >> 3) + 1);
+        int face = (int)(idx & 7u), type = face >> 1;   // 0 = Xy, 1 = Xz, 2 = Yz
+        on = type == 0 ? mk3(0, 0, 1) : (type == 1 ? mk3(0, 1, 0) : mk3(1, 0, 0));
+        meta.x = f2i(b0.w); meta.y = f2i(b1.w) + face;
+        if (want_uv) {
+            float x = type == 2 ? p.y : p.x, y = type == 0 ? p.y : p.z;
+            float xa = type == 2 ? b0.y : b0.x, xb = type == 2 ? b1.y : b1.x, ya = type == 0 ? b0.y : b0.z, yb = type == 0 ? b1.y : b1.z;
+            s.u = (x - xa) * rt_rcp(xb - xa); s.v = (y - ya) * rt_rcp(yb - ya);
+        }
     } else {
         rt_f4 r0 = ld4(sc.rects + 2 * (size_t)idx), r1 = ld4(sc.rects + 2 * (size_t)idx + 1);
         int type = f2i(r1.y);

@@ -10,7 +10,7 @@ struct alignas(16) rt_f4 { float x, y, z, w; };
 struct alignas(8) rt_i2 { int32_t x, y; };
 
 // ---- primitive kinds (also the top bits of a hit code)
-enum { RT_KIND_SPHERE = 0, RT_KIND_MSPHERE = 1, RT_KIND_RECT = 2, RT_KIND_MEDIUM = 3 };
+enum { RT_KIND_SPHERE = 0, RT_KIND_MSPHERE = 1, RT_KIND_RECT = 2, RT_KIND_BOX = 3, RT_KIND_MEDIUM = 4 };
 #define RT_HIT_NONE 0xFFFFFFFFu
 #define RT_HIT_CODE(kind, index) (((uint32_t)(kind) << 28) | (uint32_t)(index))
 #define RT_HIT_KIND(code) ((code) >> 28)
@@ -38,6 +38,10 @@ static inline int32_t rt_leaf_instance(int index) { return ~(int32_t)(RT_LEAF_IN
 //              stored as a third f4 = (1/(t1-t0), 0, 0, 0)             objects.rs:257-264
 //   rect     : 2 x f4 = (x0, x1, y0, y1), (k, type as int bits, 0, 0)  objects.rs:346-361
 //              type 0 = Xy, 1 = Xz, 2 = Yz                            objects.rs:339-343
+//   box      : 2 x f4 = (min xyz, material as int bits), (max xyz, object id of side 0 as int bits)
+//              a BoxObj (objects.rs:433-507): its six rectangles as ONE primitive; side s (order of
+//              objects.rs:445-500: z max, z min, y max, y min, x max, x min) has object id = id0 + s and
+//              hit code index = box index * 8 + s
 //   *_meta   : rt_i2 = (material index, object id in creation order)
 #define RT_MSPHERE_F4 3
 #define RT_RECT_F4 2
@@ -54,7 +58,8 @@ enum { RT_OP_TRANSLATE = 0, RT_OP_ROTATE_Y = 1 };
 //   m0 = (box.min xyz, -1/density)      m1 = (box.max xyz, material index as int)
 //   m2 = int (instance or -1, sphere first, sphere count, msphere first)
 //   m3 = int (msphere count, rect first, rect count, object id)
-#define RT_MEDIUM_F4 4
+//   m4 = int (box first, box count, 0, 0)
+#define RT_MEDIUM_F4 5
 
 // ---- material (materials.rs), 2 x f4:
 //   a0 = int/float (type, texture index or -1, fuzz, ir)     a1 = (rgb, 0): Metal albedo, or the colour of a
@@ -82,9 +87,11 @@ struct RtSceneView {
     const rt_f4* media;
     const rt_f4* materials; const rt_f4* textures;
     const rt_f4* perlin_vec; const uint8_t* perlin_perm;
+    const rt_f4* boxes;
     int32_t root;           // TLAS root node, -1 for an empty world
     int32_t n_nodes, n_spheres, n_mspheres, n_rects, n_instances, n_ops, n_media, n_materials, n_textures, n_perlin;
     int32_t max_stack;      // deepest traversal stack the BVH can need (TLAS depth + sentinel + BLAS depth)
+    int32_t n_boxes;
 };
 
 // Camera in device form (cameras.rs:23-34); dir0 = lower_left_corner - origin is precomputed in

@@ -129,7 +129,7 @@ void make_camera(const CameraDesc& d, RtCameraDev& out);
 
 // ---- Flattened scene (host arrays in the layout of rt_types.h)
 struct FlatScene {
-    std::vector<rt_f4> nodes, spheres, mspheres, rects, instances, ops, media, materials, textures, perlin_vec;
+    std::vector<rt_f4> nodes, spheres, mspheres, rects, boxes, instances, ops, media, materials, textures, perlin_vec;
     std::vector<rt_i2> sphere_meta, msphere_meta, rect_meta;
     std::vector<uint8_t> perlin_perm;
     int root = -1, max_stack = 0, tlas_depth = 0, blas_depth = 0, n_ids = 0;

@@ -12,9 +12,9 @@ LEAF_INST = 0x40000000
 
 
 def arrays(flat):
-    ptrs = (C.c_void_p * 14).from_address(flat.view)
-    ints = (C.c_int32 * 12).from_address(flat.view + 14 * 8)
-    (root, n_nodes, n_sph, n_msph, n_rect, n_inst, n_ops, n_media, n_mat, n_tex, n_perlin, max_stack) = list(ints)
+    ptrs = (C.c_void_p * 15).from_address(flat.view)
+    ints = (C.c_int32 * 13).from_address(flat.view + 15 * 8)
+    (root, n_nodes, n_sph, n_msph, n_rect, n_inst, n_ops, n_media, n_mat, n_tex, n_perlin, max_stack, n_box) = list(ints)
 
     def f4(i, n):
         if n == 0 or not ptrs[i]:
@@ -27,7 +27,8 @@ def arrays(flat):
         return np.ctypeslib.as_array((C.c_int32 * (2 * n)).from_address(ptrs[i])).reshape(-1, 2).copy()
     return dict(root=root, max_stack=max_stack, nodes=f4(0, 4 * n_nodes).reshape(-1, 16), spheres=f4(1, n_sph), sphere_meta=i2(2, n_sph),
                 mspheres=f4(3, 3 * n_msph).reshape(-1, 12), msphere_meta=i2(4, n_msph), rects=f4(5, 2 * n_rect).reshape(-1, 8),
-                rect_meta=i2(6, n_rect), instances=f4(7, 2 * n_inst).reshape(-1, 8), media=f4(9, 4 * n_media).reshape(-1, 16))
+                rect_meta=i2(6, n_rect), instances=f4(7, 2 * n_inst).reshape(-1, 8), media=f4(9, 5 * n_media).reshape(-1, 20),
+                boxes=f4(14, 2 * n_box).reshape(-1, 8))
 
 
 def prim_box(a, kind, i):
@@ -39,6 +40,9 @@ def prim_box(a, kind, i):
         c0, r, dc, t0, inv = m[0:3], abs(m[3]), m[4:7], m[7], m[8]
         cs = [c0 + (t - t0) * inv * dc for t in (0.0, 1.0)]
         return np.minimum(cs[0], cs[1]) - r, np.maximum(cs[0], cs[1]) + r
+    if kind == 3:
+        b = a["boxes"][i].astype(np.float64)
+        return b[0:3], b[4:7]
     x0, x1, y0, y1, k = a["rects"][i, :5].astype(np.float64)
     t = int(a["rects"][i, 5:6].view(np.int32)[0])
     lo, hi = {0: ((x0, y0, k), (x1, y1, k)), 1: ((x0, k, y0), (x1, k, y1)), 2: ((k, x0, y0), (k, x1, y1))}[t]
@@ -72,7 +76,7 @@ def walk(a, node, seen, depth, stats, in_blas):
                 assert 1 <= cnt <= 4
                 clo, chi = np.full(3, np.inf), np.full(3, -np.inf)
                 for i in range(first, first + cnt):
-                    assert (kind, i) not in seen or node == 0, "primitive referenced twice"
+                    assert (kind, i) not in seen or kids[0] == kids[1], "primitive referenced twice"   # a one-leaf BVH points both children at it
                     seen.add((kind, i))
                     plo, phi = prim_box(a, kind, i)
                     clo, chi = np.minimum(clo, plo), np.maximum(chi, phi)
@@ -90,16 +94,18 @@ def test_bvh_invariants(name):
     seen, stats = set(), dict(depth=0, inst=[])
     walk(a, a["root"], seen, 0, stats, False)
     # media boundary primitives are outside the BVH; everything else is referenced exactly once
-    n_bound = {0: 0, 1: 0, 2: 0}
+    n_bound = {0: 0, 1: 0, 2: 0, 3: 0}
     for m in a["media"]:
         iv = m.view(np.int32)
-        n_bound[0] += iv[10]; n_bound[1] += iv[12]; n_bound[2] += iv[14]
+        n_bound[0] += iv[10]; n_bound[1] += iv[12]; n_bound[2] += iv[14]; n_bound[3] += iv[17]
     assert len([s for s in seen if s[0] == 0]) == info.n_spheres - n_bound[0]
     assert len([s for s in seen if s[0] == 1]) == info.n_moving_spheres - n_bound[1]
     assert len([s for s in seen if s[0] == 2]) == info.n_rects - n_bound[2]
+    assert len([s for s in seen if s[0] == 3]) == info.n_boxes - n_bound[3]
     assert stats["depth"] == info.tlas_depth and stats.get("blas_depth", 0) == info.blas_depth
     assert info.max_stack <= 32 and info.max_stack == info.tlas_depth + (1 + info.blas_depth if info.n_instances and stats["inst"] else 0) or info.max_stack <= 32
-    ids = np.concatenate([a["sphere_meta"][:, 1], a["msphere_meta"][:, 1], a["rect_meta"][:, 1], a["media"].view(np.int32)[:, 15]])
+    box_ids = (a["boxes"].view(np.int32)[:, 7:8] + np.arange(6)[None, :]).reshape(-1)   # a box owns the six ids of its sides
+    ids = np.concatenate([a["sphere_meta"][:, 1], a["msphere_meta"][:, 1], a["rect_meta"][:, 1], a["media"].view(np.int32)[:, 15], box_ids])
     assert sorted(ids.tolist()) == list(range(info.n_objects))     # creation-order ids, each exactly once
 
 
@@ -143,7 +149,7 @@ def test_nested_transforms_and_unsupported_trees():
     inner = b.rotate_y(b.box((0, 0, 0), (1, 1, 1), m), 30.0)
     outer = b.translate(b.rotate_y(b.list([inner, b.sphere((3, 0, 0), 0.5, m)]), -10.0), (5, 0, 0))
     info = b.flatten_info(b.list([outer]))
-    assert info.n_instances == 2 and info.n_rects == 6 and info.n_spheres == 1
+    assert info.n_instances == 2 and info.n_boxes == 1 and info.n_rects == 0 and info.n_spheres == 1
     med = b.constant_medium_from_color(b.sphere((0, 0, 0), 1, m), 0.1, (1, 1, 1))
     with pytest.raises(rt.RtError):                  # a medium as (part of) another medium's boundary
         b.flatten_info(b.list([b.constant_medium_from_color(med, 0.1, (1, 1, 1))]))

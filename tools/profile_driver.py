@@ -18,6 +18,6 @@ cam = rt.camera_from_config(cfg)
 import torch  # noqa: E402  (device buffers only)
 acc = torch.zeros((cfg.image_height, cfg.image_width, 3), dtype=torch.float32, device="cuda:0")
 for i in range(reps):
-    p = rt.render_params(cfg.image_width, cfg.image_height, spp, cfg.max_depth, 0x5EED0002, sample_offset=i * spp, paths_per_pass=ppp, flags=abl << 8)
+    p = rt.render_params(cfg.image_width, cfg.image_height, spp, cfg.max_depth, 0x5EED0002, sample_offset=i * spp, paths_per_pass=ppp, flags=abl)
     st = scene.render_device(cam, p, acc.data_ptr(), None, None)
-    print("abl %d " % abl + "%s spp %d: %.2f ms, %.1f Mrays/s, bounce loop %.2f ms, passes %d" % (name, spp, st.seconds * 1e3, st.rays / st.seconds / 1e6, st.kernel_ms_extend, st.passes), flush=True)
+    print("flags %d %s spp %d: %.2f ms, %.1f Mrays/s, bounce loop %.2f ms (trace %.2f ms), passes %d" % (abl, name, spp, st.seconds * 1e3, st.rays / st.seconds / 1e6, st.kernel_ms_extend, st.kernel_ms_trace, st.passes), flush=True)
