@@ -30,25 +30,33 @@ HBM_PEAK_GBS = 8000.0        # HBM3E spec peak
 VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (packed FMA)
 
 # Algorithmic work per unit: FLOPs (FMA = 2) and compulsory bytes, charged per counted event.
-FLOPS = dict(node=2 * 24, sphere=26, msphere=35, rect=12, instance=35, medium=20 + 2 * 26, raygen=45,
+FLOPS = dict(node=2 * 24, sphere=26, msphere=35, rect=12, box=30, instance=35, medium=20 + 2 * 26, raygen=45,
              finalize=20, lambertian=30, metal=40, dielectric=60, light=0, isotropic=20, checker=10, noise=7 * 190 + 10)
-BYTES = dict(ray_state=184, node=64, sphere=20, msphere=40, rect=28, instance=32, shade=64, path_accum=24)
+# k_trace reads a ray (origin+time, direction+source primitive: 2 x 16 B) and writes a hit record (16 B); every
+# visited node is one 64 B record, every primitive test one record of the size below.
+TRACE_BYTES = dict(ray=32, hit=16, node=64, sphere=16, msphere=48, rect=32, box=32, instance=32)
+# the rest of a bounce (k_shade): ray 48 B + hit 16 B in, scattered ray 48 B out, contribution slot 16 B
+SHADE_BYTES = dict(ray_in=64, ray_out=48, contrib=16, material=32)
 
 
 def per_ray_work(st):
-    """Average algorithmic FLOPs and bytes per ray segment from the instrumented kernel's counters."""
+    """Average algorithmic work per ray from the instrumented kernels' counters: (k_trace FLOPs, k_trace bytes,
+    whole-bounce FLOPs, whole-bounce bytes, event counts)."""
     w = list(st.work)
     rays, paths = float(st.rays), float(st.paths)
     shades = dict(lambertian=w[8], metal=w[9], dielectric=w[10], light=w[11], isotropic=w[12])
     n_shade = sum(shades.values())
-    flops = (w[0] * FLOPS["node"] + w[1] * FLOPS["sphere"] + w[2] * FLOPS["msphere"] + w[3] * FLOPS["rect"] + w[4] * FLOPS["instance"] +
-             w[5] * FLOPS["medium"] + paths * FLOPS["raygen"] + n_shade * FLOPS["finalize"] + sum(shades[k] * FLOPS[k] for k in shades) +
-             w[13] * FLOPS["noise"] + w[14] * FLOPS["checker"])
-    byts = (rays * BYTES["ray_state"] + w[0] * BYTES["node"] + w[1] * BYTES["sphere"] + w[2] * BYTES["msphere"] + w[3] * BYTES["rect"] +
-            w[4] * BYTES["instance"] + n_shade * BYTES["shade"] + paths * BYTES["path_accum"])
-    counts = dict(nodes=w[0] / rays, sphere_tests=w[1] / rays, msphere_tests=w[2] / rays, rect_tests=w[3] / rays, instance_entries=w[4] / rays,
-                  medium_tests=w[5] / rays, miss_fraction=w[6] / rays, noise_shades=w[13] / rays, rays_per_path=rays / paths)
-    return flops / rays, byts / rays, counts
+    tests = dict(node=w[0], sphere=w[1], msphere=w[2], rect=w[3], instance=w[4], box=w[7])
+    trace_flops = sum(tests[k] * FLOPS[k] for k in tests)
+    trace_bytes = rays * (TRACE_BYTES["ray"] + TRACE_BYTES["hit"]) + sum(tests[k] * TRACE_BYTES[k] for k in tests)
+    flops = (trace_flops + w[5] * FLOPS["medium"] + paths * FLOPS["raygen"] + n_shade * FLOPS["finalize"] +
+             sum(shades[k] * FLOPS[k] for k in shades) + w[13] * FLOPS["noise"] + w[14] * FLOPS["checker"])
+    byts = (trace_bytes + rays * SHADE_BYTES["ray_in"] + n_shade * (SHADE_BYTES["ray_out"] + SHADE_BYTES["material"]) +
+            paths * (48 + SHADE_BYTES["contrib"] * 2))
+    counts = dict(nodes=w[0] / rays, sphere_tests=w[1] / rays, msphere_tests=w[2] / rays, rect_tests=w[3] / rays, box_tests=w[7] / rays,
+                  instance_entries=w[4] / rays, medium_tests=w[5] / rays, miss_fraction=w[6] / rays, noise_shades=w[13] / rays,
+                  rays_per_path=rays / paths)
+    return trace_flops / rays, trace_bytes / rays, flops / rays, byts / rays, counts
 
 
 def load_workload(name, device):
@@ -60,15 +68,17 @@ def load_workload(name, device):
 
 
 def run_steps(scene, cam, cfg, spp, steps, first_step, rank, world, accum, stream_ptr):
-    rays = kernel_ms = launches = 0
+    rays = kernel_ms = launches = trace_ms = trace_launches = 0
     for k in range(steps):
         accum.zero_()
         offset = ((first_step + k) * world + rank) * spp          # disjoint sample ranges across ranks and steps
-        p = rt.render_params(cfg.image_width, cfg.image_height, spp, cfg.max_depth, RENDER_SEED, sample_offset=offset)
+        p = rt.render_params(cfg.image_width, cfg.image_height, spp, cfg.max_depth, RENDER_SEED, sample_offset=offset,
+                             flags=rt.RT_FLAG_TIME_TRACE)   # HIP event pairs around every k_trace launch, on the render stream
         st = scene.render_device(cam, p, accum.data_ptr(), None, stream_ptr)
         reduce_accumulators(accum, 0)
         rays += int(st.rays); kernel_ms += st.kernel_ms_extend; launches += int(st.extend_launches)
-    return rays, kernel_ms, launches
+        trace_ms += st.kernel_ms_trace; trace_launches += int(st.trace_launches)
+    return rays, kernel_ms, launches, trace_ms, trace_launches
 
 
 def cpu_baseline(config_name, cfg, cam, spp, threads):
@@ -92,7 +102,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="final_scene.yml", choices=["final_scene.yml", "cornell.yml"])
     ap.add_argument("--spp-per-step", type=int, default=64)
-    ap.add_argument("--cpu-spp", type=int, default=8)
+    ap.add_argument("--cpu-spp", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second config of the metric (cornell.yml / final_scene.yml)")
     args = ap.parse_args()
@@ -122,7 +132,8 @@ def main():
         run_steps(scene, cam, cfg, args.spp_per_step, warmup, 0, rank, world, accum, stream_ptr)
         barrier()
         t0 = time.perf_counter()
-        rays, kernel_ms, launches = run_steps(scene, cam, cfg, args.spp_per_step, steps, warmup, rank, world, accum, stream_ptr)
+        rays, kernel_ms, launches, trace_ms, trace_launches = run_steps(scene, cam, cfg, args.spp_per_step, steps, warmup, rank, world, accum,
+                                                                        stream_ptr)
         barrier()
         dt = time.perf_counter() - t0
         tot = torch.tensor([dt, float(rays)], dtype=torch.float64, device=device)
@@ -133,7 +144,8 @@ def main():
         else:
             total_rays = float(rays)
         mean = float(accum.mean()) / (args.spp_per_step * world)    # rank 0: image mean of the last step (sanity only)
-        return dict(cfg=cfg, cam=cam, scene=scene, dt=dt, total_rays=total_rays, rays0=rays, kernel_ms=kernel_ms, launches=launches, mean=mean)
+        return dict(cfg=cfg, cam=cam, scene=scene, dt=dt, total_rays=total_rays, rays0=rays, kernel_ms=kernel_ms, launches=launches, trace_ms=trace_ms,
+                    trace_launches=trace_launches, mean=mean)
 
     main_run = timed(args.workload, args.steps, args.warmup)
     cfg, cam, scene = main_run["cfg"], main_run["cam"], main_run["scene"]
@@ -141,11 +153,14 @@ def main():
     if rank == 0:
         # work per ray of this workload from the instrumented kernel (outside the timed region)
         acc_np, _, cst = scene.render(cam, rt.render_params(cfg.image_width, cfg.image_height, 2, cfg.max_depth, RENDER_SEED, flags=rt.RT_FLAG_COUNTERS))
-        flops_per_ray, bytes_per_ray, counts = per_ray_work(cst)
-        k_s = main_run["kernel_ms"] * 1e-3
-        rays_per_launch = main_run["rays0"] / max(main_run["launches"], 1)
-        gbs = bytes_per_ray * main_run["rays0"] / k_s / 1e9
-        tfl = flops_per_ray * main_run["rays0"] / k_s / 1e12
+        tr_flops, tr_bytes, flops_per_ray, bytes_per_ray, counts = per_ray_work(cst)
+        rays0 = main_run["rays0"]
+        t_s = main_run["trace_ms"] * 1e-3                           # sum of the k_trace launches of the timed steps
+        b_s = main_run["kernel_ms"] * 1e-3                          # raygen-to-last-shade span of the timed steps
+        n_tr = max(main_run["trace_launches"], 1)
+        hbm_bytes = TRACE_BYTES["ray"] + TRACE_BYTES["hit"]        # per ray: the queue record in, the hit record out
+        gbs = hbm_bytes * rays0 / t_s / 1e9
+        tfl = tr_flops * rays0 / t_s / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload.replace(".yml", ""))
         if os.path.exists(tpath):
@@ -159,12 +174,20 @@ def main():
                                    % (args.workload, cfg.image_width, cfg.image_height, cfg.max_depth, args.spp_per_step, SCENE_SEED, RENDER_SEED),
                        "paths_per_step": paths, "rays_per_path": main_run["total_rays"] / args.steps / paths,
                        "parallelism": "sample-sharded x%d, reduce(SUM) to rank 0" % world, "image_mean": main_run["mean"]},
-            "roofline": {"kernel": "k_bounce (closest hit + media + scatter + queue append)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_ray": bytes_per_ray, "rays_per_launch": rays_per_launch,
-                         "avg_launch_ms": main_run["kernel_ms"] / max(main_run["launches"], 1), "launches": main_run["launches"]},
-            "roofline_valu": {"bound": "valu_fp32", "achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / VALU_PEAK_TFLOPS,
-                              "flops_per_ray": flops_per_ray},
+            "roofline": {"kernel": "k_trace (closest hit of every queued ray: BVH2 traversal + primitive tests)", "bound": "hbm",
+                         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "bytes_per_ray": hbm_bytes, "rays_per_launch": rays0 / n_tr, "bytes_per_launch": hbm_bytes * rays0 / n_tr,
+                         "avg_launch_ms": main_run["trace_ms"] / n_tr, "launches": main_run["trace_launches"],
+                         "share_of_bounce_time": t_s / b_s, "mrays_per_s_in_kernel": rays0 / t_s / 1e6,
+                         "scene_bytes_fetched_per_ray": tr_bytes - hbm_bytes,
+                         "note": "algorithmic HBM bytes = 32 B ray record in + 16 B hit record out per ray; the node and primitive records a ray "
+                                 "visits (scene_bytes_fetched_per_ray) come from the LDS copy of the <1 MB scene, so the kernel is bound by "
+                                 "dependent-instruction latency of divergent traversal, not by HBM or VALU throughput"},
+            "roofline_valu": {"kernel": "k_trace", "bound": "valu_fp32", "achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": tfl / VALU_PEAK_TFLOPS, "flops_per_ray": tr_flops},
+            "bounce_total": {"kernels": "k_trace + k_shade", "ms": main_run["kernel_ms"], "launch_pairs": main_run["launches"],
+                             "flops_per_ray": flops_per_ray, "bytes_per_ray": bytes_per_ray,
+                             "achieved_gbs": bytes_per_ray * rays0 / b_s / 1e9, "achieved_tflops": flops_per_ray * rays0 / b_s / 1e12},
             "work_per_ray": counts,
         }
     if not args.no_secondary:

@@ -39,10 +39,10 @@
     } while (0)
 
 // ------------------------------------------------------------------ device side
-struct LdsStack {  // one column of the block's LDS stack: entry i of thread t lives at [i][t]
-    int* base; int depth;
-    __host__ __device__ void set(int i, int v) { base[i * RT_BLOCK] = v; }
-    __host__ __device__ int get(int i) const { return base[i * RT_BLOCK]; }
+struct LdsStack {  // one column of the block's LDS stack: entry i of thread t lives at [i][t]; stride = threads per block
+    int* base; int depth; int stride;
+    __host__ __device__ void set(int i, int v) { base[i * stride] = v; }
+    __host__ __device__ int get(int i) const { return base[i * stride]; }
     __host__ __device__ int cap() const { return depth; }
 };
 
@@ -74,12 +74,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev
 }
 
 // Node records: the first n_cached nodes (the top levels, nodes are numbered breadth-first) come from LDS.
+typedef float __attribute__((ext_vector_type(4))) rt_vf4;
+typedef __attribute__((address_space(3))) const rt_vf4 lds_f4;   // keeps LDS reads ds_read_b128 (a generic pointer makes them flat loads)
+__device__ __forceinline__ rt_f4 lds_ld4(lds_f4* p) { rt_vf4 v = *p; rt_f4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
 struct CachedNodes {
-    const rt_f4* global; const rt_f4* lds; int32_t n_cached;
+    const rt_f4* global; lds_f4* lds; int32_t n_cached;
     __device__ __forceinline__ void get(int32_t n, rt_f4 q[4]) const {
         if (n < n_cached) {
-            const rt_f4* p = lds + 4 * n;
-            q[0] = p[0]; q[1] = p[1]; q[2] = p[2]; q[3] = p[3];
+            lds_f4* p = lds + 4 * n;
+            q[0] = lds_ld4(p); q[1] = lds_ld4(p + 1); q[2] = lds_ld4(p + 2); q[3] = lds_ld4(p + 3);
         } else {
             const rt_f4* p = global + 4 * (size_t)n;
             q[0] = ld4(p); q[1] = ld4(p + 1); q[2] = ld4(p + 2); q[3] = ld4(p + 3);
@@ -92,18 +95,18 @@ struct CachedNodes {
 // the idle lanes take the next rays of the region through one wave-aggregated atomic on the region's cursor.  Rays
 // that need 100+ node visits therefore do not hold 63 finished lanes idle, which is what a ray-per-thread launch
 // costs on 64-wide waves.  Dynamic LDS: [n_cached nodes][stack_depth x RT_BLOCK ints].
-template <bool STATS>
-__global__ __launch_bounds__(RT_BLOCK) void k_trace(RtSceneView sc, uint32_t cap, const uint32_t* counts_in, uint32_t* cursors,
+template <bool STATS, int TB>
+__global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, uint32_t cap, const uint32_t* counts_in, uint32_t* cursors,
                                                     const rt_f4* ia, const rt_f4* ib, rt_f4* hits, int n_cached, int stack_depth,
                                                     int refill_lanes, unsigned long long* work) {
     if (counts_in[blockIdx.y * RT_COUNT_STRIDE] == 0) return;
     extern __shared__ __align__(16) unsigned char smem[];
     rt_f4* s_nodes = reinterpret_cast<rt_f4*>(smem);
     int* s_stack = reinterpret_cast<int*>(smem + (size_t)n_cached * 64);
-    for (int i = threadIdx.x; i < n_cached * 4; i += RT_BLOCK) s_nodes[i] = ld4(sc.nodes + i);
+    for (int i = threadIdx.x; i < n_cached * 4; i += TB) s_nodes[i] = ld4(sc.nodes + i);
     __syncthreads();
-    LdsStack stk; stk.base = s_stack + threadIdx.x; stk.depth = stack_depth;
-    CachedNodes nodes; nodes.global = sc.nodes; nodes.lds = s_nodes; nodes.n_cached = n_cached;
+    LdsStack stk; stk.base = s_stack + threadIdx.x; stk.depth = stack_depth; stk.stride = TB;
+    CachedNodes nodes; nodes.global = sc.nodes; nodes.lds = (lds_f4*)s_nodes; nodes.n_cached = n_cached;
 
     const uint32_t region = blockIdx.y;
     const uint32_t n = counts_in[region * RT_COUNT_STRIDE];
@@ -118,10 +121,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(RtSceneView sc, uint32_t cap
     RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
     RtCounters cnt = {0, 0, 0, 0, 0, 0};
 
+    uint32_t dbg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // STATS: wave-level iteration counts (lane 0 of each wave's live set)
     for (;;) {
         unsigned long long am = __ballot(active);
         int n_idle = 64 - __popcll(am);
+        if (STATS && (threadIdx.x & 63) == 0) { dbg[0]++; dbg[1] += 64 - n_idle; }
         if (!exhausted && (n_idle >= refill_lanes || am == 0)) {
+            if (STATS && (threadIdx.x & 63) == 0) dbg[2]++;
             unsigned long long im = ~am;
             uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
             uint32_t base = 0;
@@ -142,11 +148,25 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(RtSceneView sc, uint32_t cap
         }
         if (am == 0) break;
         if (active) {
-            while (rt_is_inner(tv.cur)) rt_node_step<STATS>(nodes, tv, RT_TMIN, hit, stk, &cnt);
+            while (rt_is_inner(tv.cur)) {
+                if (STATS) { unsigned long long ex = __ballot(true); if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) dbg[3]++; }
+                rt_node_step<STATS>(nodes, tv, RT_TMIN, hit, stk, &cnt);
+            }
             if (tv.cur >= 0) {
                 if (tv.cur != RT_EMPTY_STACK) rt_sentinel_step(wo, wd, tv, stk);
             } else {
-                do rt_leaf_step<STATS>(sc, wo, wd, time, RT_TMIN, src, tv, hit, stk, &cnt); while (tv.cur < 0);
+                do {
+                    if (STATS) {
+                        unsigned long long ex = __ballot(true);
+                        uint32_t x = ~(uint32_t)tv.cur;
+                        int kind = (x & RT_LEAF_INSTANCE_BIT) ? 4 : (int)((x >> 28) & 3u);
+                        bool first = (int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1;
+                        if (first) dbg[4]++;
+                        for (int k = 0; k < 5; ++k) { unsigned long long bk = __ballot(kind == k); if (first && bk) dbg[5 + k]++; }
+                        dbg[10]++;
+                    }
+                    rt_leaf_step<STATS>(sc, wo, wd, time, RT_TMIN, src, tv, hit, stk, &cnt);
+                } while (tv.cur < 0);
             }
             if (tv.cur == RT_EMPTY_STACK) {
                 *reinterpret_cast<float4*>(hits + slot) = make_float4(hit.t, i2f((int)hit.code), i2f(hit.inst), 0.0f);
@@ -158,6 +178,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace(RtSceneView sc, uint32_t cap
         atomicAdd(work + 0, (unsigned long long)cnt.nodes); atomicAdd(work + 1, (unsigned long long)cnt.spheres);
         atomicAdd(work + 2, (unsigned long long)cnt.mspheres); atomicAdd(work + 3, (unsigned long long)cnt.rects);
         atomicAdd(work + 4, (unsigned long long)cnt.instances); atomicAdd(work + 7, (unsigned long long)cnt.boxes);
+        for (int k = 0; k < 12; ++k) if (dbg[k]) atomicAdd(work + 16 + k, (unsigned long long)dbg[k]);
     }
 }
 
@@ -263,7 +284,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const rt_f4* contrib, i
 __global__ __launch_bounds__(RT_BLOCK) void k_primary(RtSceneView sc, RtCameraDev cam, RtFrameDev fr, uint32_t sample, int32_t* ids,
                                                       float* ts, float* normals, int32_t* fronts, float* uvs) {
     __shared__ int s_stack[RT_STACK_DEPTH * RT_BLOCK];
-    LdsStack stk; stk.base = s_stack + threadIdx.x; stk.depth = RT_STACK_DEPTH;
+    LdsStack stk; stk.base = s_stack + threadIdx.x; stk.depth = RT_STACK_DEPTH; stk.stride = RT_BLOCK;
     uint32_t pixel = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (pixel >= (uint32_t)fr.n_pixels) return;
     v3 o, d; float time;
@@ -287,7 +308,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(RtSceneView sc, RtCameraDe
 __global__ __launch_bounds__(RT_BLOCK) void k_scatter_rays(RtSceneView sc, const float* rays, int n, uint32_t pixel0, uint32_t sample, int bounce,
                                                            uint32_t key0, uint32_t key1, float* out) {
     __shared__ int s_stack[RT_STACK_DEPTH * RT_BLOCK];
-    LdsStack stk; stk.base = s_stack + threadIdx.x; stk.depth = RT_STACK_DEPTH;
+    LdsStack stk; stk.base = s_stack + threadIdx.x; stk.depth = RT_STACK_DEPTH; stk.stride = RT_BLOCK;
     int i = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i >= n) return;
     const float* r = rays + 7 * (size_t)i;
@@ -329,7 +350,55 @@ struct RtScene {
     int lds_stack = 1;                     // stack entries per ray in k_trace
     int refill_lanes = 16;                 // idle lanes of a wave that trigger a refill in k_trace
     int trace_blocks_per_cu = 4;           // resident k_trace blocks per CU (0 = as many as the LDS allows); more thrash the 32 KB L1
+    int trace_block = 256;                 // threads per k_trace block (256 or 1024)
 };
+
+// k_trace comes in two block shapes: 1024 threads (one block per CU, its 16 waves share one LDS copy of the node array)
+// and 256 threads (several blocks per CU, each with a small copy of the top of the tree).
+static void launch_trace(RtScene* s, bool stats, dim3 grid, hipStream_t st, uint32_t cap, const uint32_t* cin, uint32_t* cursors,
+                         const rt_f4* qa, const rt_f4* qb) {
+#define RT_LAUNCH_TRACE(STATS_, TB_)                                                                                         \
+    hipLaunchKernelGGL((k_trace<STATS_, TB_>), grid, dim3(TB_), (size_t)s->lds_bytes, st, s->view, cap, cin, cursors, qa, qb, \
+                       s->hits, s->lds_nodes, s->lds_stack, s->refill_lanes, s->work)
+    if (s->trace_block == 1024) { if (stats) RT_LAUNCH_TRACE(true, 1024); else RT_LAUNCH_TRACE(false, 1024); }
+    else { if (stats) RT_LAUNCH_TRACE(true, 256); else RT_LAUNCH_TRACE(false, 256); }
+#undef RT_LAUNCH_TRACE
+}
+
+// Chooses k_trace's block shape and LDS plan for a scene.  LDS per block = [cached nodes][stack entries x threads].
+static int plan_trace(RtScene* s) {
+    const int n_nodes = s->view.n_nodes;
+    const int stack = std::max(1, s->flat.max_stack);
+    const int lds_cu = 160 * 1024;
+    s->lds_stack = stack;
+    const char* env_tb = std::getenv("RT_TRACE_BLOCK");
+    int want = env_tb ? std::atoi(env_tb) : 1024;
+    const int big_stack = stack * 1024 * (int)sizeof(int);
+    if (want == 1024 && big_stack + 64 <= lds_cu - 1024) {
+        int room = (lds_cu - 1024 - big_stack) / 64;
+        s->trace_block = 1024;
+        s->lds_nodes = std::max(0, std::min(n_nodes, room));
+        s->lds_bytes = big_stack + s->lds_nodes * 64;
+        s->trace_blocks_per_cu = 1;
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
+        if (e1 == hipSuccess && e2 == hipSuccess) return RT_OK;
+        (void)hipGetLastError();   // this device does not give one block that much LDS: use the small blocks
+    }
+    const char* env = std::getenv("RT_LDS_BUDGET_KB");
+    int budget = (env ? std::max(4, std::min(64, std::atoi(env))) : 40) * 1024;
+    int stack_bytes = stack * 256 * (int)sizeof(int);
+    s->trace_block = 256;
+    s->lds_nodes = std::max(0, std::min(n_nodes, (budget - stack_bytes) / 64));
+    s->lds_bytes = stack_bytes + s->lds_nodes * 64;
+    s->trace_blocks_per_cu = 4;
+    if (const char* e3 = std::getenv("RT_TRACE_BLOCKS_PER_CU")) s->trace_blocks_per_cu = std::max(0, std::min(8, std::atoi(e3)));
+    if (s->lds_bytes > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+    }
+    return RT_OK;
+}
 
 template <class T>
 static int upload(RtScene* s, const std::vector<T>& v, const T** out) {
@@ -354,7 +423,7 @@ static void free_workspace(RtScene* s) {
 }
 static int ensure_workspace(RtScene* s, size_t n_paths) {
     if (!s->counts) { HIP_TRY(hipMalloc((void**)&s->counts, (size_t)2 * (RT_MAX_BOUNCES + 2) * RT_SHARDS * RT_COUNT_STRIDE * sizeof(uint32_t))); }
-    if (!s->work) { HIP_TRY(hipMalloc((void**)&s->work, 16 * sizeof(unsigned long long))); }
+    if (!s->work) { HIP_TRY(hipMalloc((void**)&s->work, 32 * sizeof(unsigned long long))); }
     if (!s->ev0) { HIP_TRY(hipEventCreate(&s->ev0)); HIP_TRY(hipEventCreate(&s->ev1)); }
     if (s->ws_paths >= n_paths) return RT_OK;
     free_workspace(s);
@@ -445,15 +514,8 @@ int rt_scene_create(const RtBuilder* b, RtObj world, int device, RtScene** out) 
         if ((r = upload(s, f.perlin_perm, &v.perlin_perm))) return r;
         if ((r = upload(s, f.boxes, &v.boxes))) return r;
         s->view = v;
-        // LDS plan of k_trace: the exact stack the BVH can need, the rest of a 32 KB block budget for the top nodes
-        const char* env = std::getenv("RT_LDS_BUDGET_KB");
-        int budget = (env ? std::max(4, std::min(64, std::atoi(env))) : 40) * 1024;
-        s->lds_stack = std::max(1, f.max_stack);
-        int stack_bytes = s->lds_stack * RT_BLOCK * (int)sizeof(int);
-        s->lds_nodes = std::max(0, std::min(v.n_nodes, (budget - stack_bytes) / 64));
-        s->lds_bytes = stack_bytes + s->lds_nodes * 64;
+        if ((r = plan_trace(s))) return r;
         if (const char* e2 = std::getenv("RT_REFILL_LANES")) s->refill_lanes = std::max(1, std::min(64, std::atoi(e2)));
-        if (const char* e3 = std::getenv("RT_TRACE_BLOCKS_PER_CU")) s->trace_blocks_per_cu = std::max(0, std::min(8, std::atoi(e3)));
         return RT_OK;
     }();
     if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
@@ -530,7 +592,7 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     const int lds_limit = std::max(1, std::min(8, (160 * 1024) / std::max(1, s->lds_bytes)));
     const int blocks_per_cu = s->trace_blocks_per_cu > 0 ? std::min(s->trace_blocks_per_cu, lds_limit) : lds_limit;
     dim3 tgrid((unsigned)std::max(1, (std::max(1, s->n_cu) * blocks_per_cu + RT_SHARDS - 1) / RT_SHARDS), RT_SHARDS);
-    if (instrumented) HIP_TRY(hipMemsetAsync(s->work, 0, 16 * sizeof(unsigned long long), st));
+    if (instrumented) HIP_TRY(hipMemsetAsync(s->work, 0, 32 * sizeof(unsigned long long), st));
 
     for (int done = 0; done < p->spp;) {
         int chunk = std::min(chunk_max, p->spp - done);
@@ -553,12 +615,7 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
             uint32_t* cout = s->counts + (size_t)(b + 1) * RT_SHARDS * RT_COUNT_STRIDE;
             uint32_t* cursors = s->counts + (size_t)(RT_MAX_BOUNCES + 2 + b) * RT_SHARDS * RT_COUNT_STRIDE;
             if (time_trace) HIP_TRY(hipEventRecord(s->ev_trace[2 * (b - 1)], st));
-            if (instrumented)
-                hipLaunchKernelGGL(k_trace<true>, tgrid, dim3(RT_BLOCK), (size_t)s->lds_bytes, st, s->view, cap, cin, cursors, s->qa[in], s->qb[in],
-                                   s->hits, s->lds_nodes, s->lds_stack, s->refill_lanes, s->work);
-            else
-                hipLaunchKernelGGL(k_trace<false>, tgrid, dim3(RT_BLOCK), (size_t)s->lds_bytes, st, s->view, cap, cin, cursors, s->qa[in], s->qb[in],
-                                   s->hits, s->lds_nodes, s->lds_stack, s->refill_lanes, s->work);
+            launch_trace(s, instrumented, tgrid, st, cap, cin, cursors, s->qa[in], s->qb[in]);
             if (time_trace) HIP_TRY(hipEventRecord(s->ev_trace[2 * (b - 1) + 1], st));
             if (instrumented)
                 hipLaunchKernelGGL(k_shade<true>, bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, cin, cout, s->qa[in], s->qb[in], s->qc[in], s->hits,
@@ -597,6 +654,13 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         unsigned long long w[16];
         HIP_TRY(hipMemcpy(w, s->work, sizeof(w), hipMemcpyDeviceToHost));
         for (int i = 0; i < 16; ++i) local.work[i] = w[i];
+        if (std::getenv("RT_DEBUG_WORK")) {
+            unsigned long long w2[16];
+            HIP_TRY(hipMemcpy(w2, s->work + 16, sizeof(w2), hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "k_trace wave counters: outer %llu (active lanes %llu) refills %llu node-iters %llu leaf-iters %llu "
+                         "[sphere %llu msphere %llu rect %llu box %llu inst %llu] leaf lane-iters %llu | lane node-steps %llu\n",
+                         w2[0], w2[1], w2[2], w2[3], w2[4], w2[5], w2[6], w2[7], w2[8], w2[9], w2[10], w[0]);
+        }
     }
     local.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     if (stats) *stats = local;

@@ -280,6 +280,9 @@ struct RtCounters { uint32_t nodes, spheres, mspheres, rects, instances, boxes; 
 // persistent kernel (which refills finished lanes with new rays between steps) share them.
 //   Stack : set(i, v) / get(i) on an int array of cap() entries.      Nodes : get(node, q[4]) fetches the 64-byte node record.
 struct RtTrav { v3 o, d, inv; int32_t inst, sp, cur; };
+RT_HD void rt_trav_ray(RtTrav& tv, v3 o, v3 d) {
+    tv.o = o; tv.d = d; tv.inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
+}
 
 struct RtGlobalNodes {
     const rt_f4* nodes;
@@ -292,7 +295,7 @@ struct RtGlobalNodes {
 RT_HD bool rt_is_inner(int32_t cur) { return (uint32_t)cur < (uint32_t)RT_SENTINEL; }
 
 RT_HD void rt_trav_begin(const RtSceneView& sc, v3 wo, v3 wd, RtTrav& tv) {
-    tv.o = wo; tv.d = wd; tv.inv = mk3(rt_rcp(wd.x), rt_rcp(wd.y), rt_rcp(wd.z));
+    rt_trav_ray(tv, wo, wd);
     tv.inst = -1; tv.sp = 0; tv.cur = sc.root < 0 ? RT_EMPTY_STACK : sc.root;
 }
 template <class Stack>
@@ -320,7 +323,7 @@ RT_HD void rt_node_step(const Nodes& nodes, RtTrav& tv, float tmin, const RtHit&
 // tv.cur is the sentinel pushed when an instance was entered: back to the world-space ray.
 template <class Stack>
 RT_HD void rt_sentinel_step(v3 wo, v3 wd, RtTrav& tv, Stack& stk) {
-    tv.o = wo; tv.d = wd; tv.inv = mk3(rt_rcp(wd.x), rt_rcp(wd.y), rt_rcp(wd.z)); tv.inst = -1;
+    rt_trav_ray(tv, wo, wd); tv.inst = -1;
     tv.cur = rt_pop(tv, stk);
 }
 
@@ -335,8 +338,7 @@ RT_HD void rt_leaf_step(const RtSceneView& sc, v3 wo, v3 wd, float time, float t
         if (tv.sp < stk.cap()) stk.set(tv.sp++, RT_SENTINEL);
         tv.inst = ii;
         if (STATS) wc->instances++;
-        tv.o = rt_to_object_point(i0, i1, wo); tv.d = rt_to_object_dir(i0, wd);
-        tv.inv = mk3(rt_rcp(tv.d.x), rt_rcp(tv.d.y), rt_rcp(tv.d.z));
+        rt_trav_ray(tv, rt_to_object_point(i0, i1, wo), rt_to_object_dir(i0, wd));
         tv.cur = f2i(i1.y);
         return;
     }

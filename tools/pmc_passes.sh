@@ -5,6 +5,7 @@ set -u
 OUT=$1; CFG=$2; SPP=$3; REPS=$4
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 export TMPDIR=/tmp
+case "$OUT" in /*) ;; *) OUT="$PWD/$OUT" ;; esac
 mkdir -p "$OUT"
 cd /tmp
 i=0

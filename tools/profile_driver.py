@@ -7,6 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ray_tracing_amd as rt  # noqa: E402
 
+if os.environ.get("RT_VARIANT_LIB"):   # A/B runs: a library built with other -D flags (tools/build_variant.sh)
+    rt.LIB_PATH = os.path.join(ROOT, os.environ["RT_VARIANT_LIB"])
 name, spp, reps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 ppp = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 abl = int(sys.argv[5]) if len(sys.argv) > 5 else 0
@@ -21,3 +23,4 @@ for i in range(reps):
     p = rt.render_params(cfg.image_width, cfg.image_height, spp, cfg.max_depth, 0x5EED0002, sample_offset=i * spp, paths_per_pass=ppp, flags=abl)
     st = scene.render_device(cam, p, acc.data_ptr(), None, None)
     print("flags %d %s spp %d: %.2f ms, %.1f Mrays/s, bounce loop %.2f ms (trace %.2f ms), passes %d" % (abl, name, spp, st.seconds * 1e3, st.rays / st.seconds / 1e6, st.kernel_ms_extend, st.kernel_ms_trace, st.passes), flush=True)
+print("library:", [l.split()[-1] for l in open("/proc/self/maps") if "ray_tracing_amd" in l and l.rstrip().endswith(".so")][:1], flush=True)
