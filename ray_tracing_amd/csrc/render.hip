@@ -41,8 +41,9 @@
 // ------------------------------------------------------------------ device side
 struct LdsStack {  // one column of the block's LDS stack: entry i of thread t lives at [i][t]; stride = threads per block
     int* base; int depth; int stride;
-    __host__ __device__ void set(int i, int v) { base[i * stride] = v; }
-    __host__ __device__ int get(int i) const { return base[i * stride]; }
+    __host__ __device__ void put(int i, int, int, int code) { base[i * stride] = code; }
+    __host__ __device__ void put_sentinel(int i) { base[i * stride] = RT_SENTINEL; }
+    __host__ __device__ int take(int i) const { return base[i * stride]; }
     __host__ __device__ int cap() const { return depth; }
 };
 
@@ -73,14 +74,31 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev
     }
 }
 
-// Node records: the first n_cached nodes (the top levels, nodes are numbered breadth-first) come from LDS.
+// ---- k_trace: closest surface hit of every queued ray
+// LDS plan of one k_trace block (host: plan_trace).  Offsets are in 16-byte records from the start of the block's
+// dynamic LDS; an offset < 0 leaves that array in global memory.  Layout: [nodes][primitive arrays][stack].
+struct RtTracePlan {
+    int32_t n_nodes_lds;                                                  // nodes [0, n) are served from LDS
+    int32_t off_spheres, off_mspheres, off_rects, off_boxes, off_instances;
+    int32_t off_stack;                                                    // first record of the stack
+    int32_t stack_cap;                                                    // stack entries per lane
+    int32_t wide_stack;                                                   // 1: 32-bit entries, 0: 16-bit entries (TraceStack)
+    int32_t resident;                                                     // 1: all nodes and all primitive arrays are in LDS
+    int32_t refill_lanes;                                                 // idle lanes of a wave that trigger a refill
+};
+
 typedef float __attribute__((ext_vector_type(4))) rt_vf4;
 typedef __attribute__((address_space(3))) const rt_vf4 lds_f4;   // keeps LDS reads ds_read_b128 (a generic pointer makes them flat loads)
+typedef __attribute__((address_space(3))) int lds_int;
 __device__ __forceinline__ rt_f4 lds_ld4(lds_f4* p) { rt_vf4 v = *p; rt_f4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
-struct CachedNodes {
-    const rt_f4* global; lds_f4* lds; int32_t n_cached;
+
+// RESIDENT = the whole node array and every primitive array are in LDS: the accessors then have no global-memory path at
+// all, which matters beyond the saved branch -- with no other VMEM load in the traversal loop the compiler has no reason
+// to wait on vmcnt there, so the prefetch of the next ray batch really stays in flight.
+template <bool RESIDENT> struct TraceNodes {   // node records: the breadth-first prefix [0, n_lds) from LDS, the rest from global memory
+    const rt_f4* global; lds_f4* lds; int32_t n_lds;
     __device__ __forceinline__ void get(int32_t n, rt_f4 q[4]) const {
-        if (n < n_cached) {
+        if (RESIDENT || n < n_lds) {
             lds_f4* p = lds + 4 * n;
             q[0] = lds_ld4(p); q[1] = lds_ld4(p + 1); q[2] = lds_ld4(p + 2); q[3] = lds_ld4(p + 3);
         } else {
@@ -89,29 +107,83 @@ struct CachedNodes {
         }
     }
 };
+template <bool RESIDENT> struct TracePrims {   // primitive records: every array is either wholly in LDS (offset >= 0) or read from global memory
+    const RtSceneView* sc; lds_f4* lds; int32_t o_sph, o_msph, o_rect, o_box, o_inst;
+    __device__ __forceinline__ rt_f4 sphere(uint32_t i) const { return (RESIDENT || o_sph >= 0) ? lds_ld4(lds + o_sph + i) : ld4(sc->spheres + i); }
+    __device__ __forceinline__ void msphere(uint32_t i, rt_f4& m0, rt_f4& m1, rt_f4& m2) const {
+        if (RESIDENT || o_msph >= 0) { lds_f4* m = lds + o_msph + 3 * i; m0 = lds_ld4(m); m1 = lds_ld4(m + 1); m2 = lds_ld4(m + 2); }
+        else { const rt_f4* m = sc->mspheres + 3 * (size_t)i; m0 = ld4(m); m1 = ld4(m + 1); m2 = ld4(m + 2); }
+    }
+    __device__ __forceinline__ void pair(int32_t off, const rt_f4* g, uint32_t i, rt_f4& r0, rt_f4& r1) const {
+        if (RESIDENT || off >= 0) { lds_f4* m = lds + off + 2 * i; r0 = lds_ld4(m); r1 = lds_ld4(m + 1); }
+        else { r0 = ld4(g + 2 * (size_t)i); r1 = ld4(g + 2 * (size_t)i + 1); }
+    }
+    __device__ __forceinline__ void rect(uint32_t i, rt_f4& r0, rt_f4& r1) const { pair(o_rect, sc->rects, i, r0, r1); }
+    __device__ __forceinline__ void box(uint32_t i, rt_f4& b0, rt_f4& b1) const { pair(o_box, sc->boxes, i, b0, b1); }
+    __device__ __forceinline__ void instance(uint32_t i, rt_f4& i0, rt_f4& i1) const { pair(o_inst, sc->instances, i, i0, i1); }
+};
+// Per-lane traversal stack in LDS, [entry][thread].  WIDE = false: 16-bit entries that name the postponed child by its
+// parent (node << 1 | which); the child code is re-read from the parent's record, which must be in LDS.  Half the LDS of
+// the 32-bit form, which is what lets a small scene's primitives sit in LDS beside its nodes.
+typedef __attribute__((address_space(3))) unsigned short lds_u16;
+template <bool WIDE> struct TraceStack;
+template <> struct TraceStack<true> {
+    lds_int* base; int depth, stride;
+    __device__ __forceinline__ void put(int i, int, int, int code) { base[i * stride] = code; }
+    __device__ __forceinline__ void put_sentinel(int i) { base[i * stride] = RT_SENTINEL; }
+    __device__ __forceinline__ int take(int i) const { return base[i * stride]; }
+    __device__ __forceinline__ int cap() const { return depth; }
+};
+template <> struct TraceStack<false> {
+    lds_u16* base; lds_int* node_words; int depth, stride;
+    __device__ __forceinline__ void put(int i, int node, int which, int) { base[i * stride] = (unsigned short)((node << 1) | which); }
+    __device__ __forceinline__ void put_sentinel(int i) { base[i * stride] = (unsigned short)0xFFFFu; }
+    __device__ __forceinline__ int take(int i) const {
+        uint32_t e = base[i * stride];
+        return e == 0xFFFFu ? RT_SENTINEL : node_words[(e >> 1) * 16u + 12u + (e & 1u)];
+    }
+    __device__ __forceinline__ int cap() const { return depth; }
+};
+template <bool WIDE> __device__ __forceinline__ TraceStack<WIDE> make_stack(unsigned char* smem, int off_stack, int depth, int threads);
+template <> __device__ __forceinline__ TraceStack<true> make_stack<true>(unsigned char* smem, int off_stack, int depth, int threads) {
+    TraceStack<true> s; s.base = (lds_int*)(smem + (size_t)off_stack * 16) + threadIdx.x; s.depth = depth; s.stride = threads; return s;
+}
+template <> __device__ __forceinline__ TraceStack<false> make_stack<false>(unsigned char* smem, int off_stack, int depth, int threads) {
+    TraceStack<false> s; s.base = (lds_u16*)(smem + (size_t)off_stack * 16) + threadIdx.x; s.node_words = (lds_int*)smem;
+    s.depth = depth; s.stride = threads; return s;
+}
 
-// Stage 1 of a bounce: closest surface hit of every queued ray (lib.rs:63 without the media).
-// Persistent waves: a lane that has finished its ray waits until `refill_lanes` lanes of its wave are idle, then
-// the idle lanes take the next rays of the region through one wave-aggregated atomic on the region's cursor.  Rays
-// that need 100+ node visits therefore do not hold 63 finished lanes idle, which is what a ray-per-thread launch
-// costs on 64-wide waves.  Dynamic LDS: [n_cached nodes][stack_depth x RT_BLOCK ints].
-template <bool STATS, int TB>
-__global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, uint32_t cap, const uint32_t* counts_in, uint32_t* cursors,
-                                                    const rt_f4* ia, const rt_f4* ib, rt_f4* hits, int n_cached, int stack_depth,
-                                                    int refill_lanes, unsigned long long* work) {
-    if (counts_in[blockIdx.y * RT_COUNT_STRIDE] == 0) return;
-    extern __shared__ __align__(16) unsigned char smem[];
-    rt_f4* s_nodes = reinterpret_cast<rt_f4*>(smem);
-    int* s_stack = reinterpret_cast<int*>(smem + (size_t)n_cached * 64);
-    for (int i = threadIdx.x; i < n_cached * 4; i += TB) s_nodes[i] = ld4(sc.nodes + i);
-    __syncthreads();
-    LdsStack stk; stk.base = s_stack + threadIdx.x; stk.depth = stack_depth; stk.stride = TB;
-    CachedNodes nodes; nodes.global = sc.nodes; nodes.lds = (lds_f4*)s_nodes; nodes.n_cached = n_cached;
-
+// Persistent grid, one ray per lane.  The scene (node array and, when they fit, the primitive arrays) is copied into
+// the block's LDS once; traversal then touches global memory only for the ray records in and the hit records out.
+// A lane that has finished its ray waits until `refill_lanes` lanes of its wave are idle; the idle lanes then take the
+// next rays of the region through one wave-aggregated atomic on the region's cursor (ballot + mbcnt ranks).  A wave
+// therefore never drains to a few long rays, which is what a ray-per-thread launch costs on 64-wide waves.
+template <bool STATS, int TB, bool WIDE, bool RESIDENT>
+__global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, uint32_t cap, const uint32_t* counts_in, uint32_t* cursors,
+                                              const rt_f4* ia, const rt_f4* ib, rt_f4* hits, unsigned long long* work) {
     const uint32_t region = blockIdx.y;
     const uint32_t n = counts_in[region * RT_COUNT_STRIDE];
+    if (n == 0) return;
+    extern __shared__ __align__(16) unsigned char smem[];
+    {   // scene -> LDS
+        rt_f4* dst = reinterpret_cast<rt_f4*>(smem);
+        for (int i = threadIdx.x; i < plan.n_nodes_lds * 4; i += TB) dst[i] = ld4(sc.nodes + i);
+        if (plan.off_spheres >= 0) for (int i = threadIdx.x; i < sc.n_spheres; i += TB) dst[plan.off_spheres + i] = ld4(sc.spheres + i);
+        if (plan.off_mspheres >= 0) for (int i = threadIdx.x; i < sc.n_mspheres * 3; i += TB) dst[plan.off_mspheres + i] = ld4(sc.mspheres + i);
+        if (plan.off_rects >= 0) for (int i = threadIdx.x; i < sc.n_rects * 2; i += TB) dst[plan.off_rects + i] = ld4(sc.rects + i);
+        if (plan.off_boxes >= 0) for (int i = threadIdx.x; i < sc.n_boxes * 2; i += TB) dst[plan.off_boxes + i] = ld4(sc.boxes + i);
+        if (plan.off_instances >= 0) for (int i = threadIdx.x; i < sc.n_instances * 2; i += TB) dst[plan.off_instances + i] = ld4(sc.instances + i);
+    }
+    __syncthreads();
+    lds_f4* lds = (lds_f4*)smem;
+    TraceNodes<RESIDENT> nodes; nodes.global = sc.nodes; nodes.lds = lds; nodes.n_lds = plan.n_nodes_lds;
+    TracePrims<RESIDENT> prims; prims.sc = &sc; prims.lds = lds;
+    prims.o_sph = plan.off_spheres; prims.o_msph = plan.off_mspheres; prims.o_rect = plan.off_rects; prims.o_box = plan.off_boxes; prims.o_inst = plan.off_instances;
+    TraceStack<WIDE> stk = make_stack<WIDE>(smem, plan.off_stack, plan.stack_cap, TB);
+
     uint32_t* cursor = cursors + region * RT_COUNT_STRIDE;
     ia += (size_t)region * cap; ib += (size_t)region * cap; hits += (size_t)region * cap;
+    const uint32_t lane = threadIdx.x & 63u;
 
     bool active = false, exhausted = false;
     uint32_t slot = 0, src = RT_HIT_NONE;
@@ -120,14 +192,14 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, uint32_t cap, cons
     RtTrav tv; tv.o = wo; tv.d = wd; tv.inv = wd; tv.inst = -1; tv.sp = 0; tv.cur = RT_EMPTY_STACK;
     RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
     RtCounters cnt = {0, 0, 0, 0, 0, 0};
+    uint32_t dbg[4] = {0, 0, 0, 0};   // STATS: wave-level counts of outer iterations, refills, node-loop and leaf-loop iterations
 
-    uint32_t dbg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // STATS: wave-level iteration counts (lane 0 of each wave's live set)
     for (;;) {
         unsigned long long am = __ballot(active);
         int n_idle = 64 - __popcll(am);
-        if (STATS && (threadIdx.x & 63) == 0) { dbg[0]++; dbg[1] += 64 - n_idle; }
-        if (!exhausted && (n_idle >= refill_lanes || am == 0)) {
-            if (STATS && (threadIdx.x & 63) == 0) dbg[2]++;
+        if (STATS && lane == 0) dbg[0]++;
+        if (!exhausted && (n_idle >= plan.refill_lanes || am == 0)) {
+            if (STATS && lane == 0) dbg[1]++;
             unsigned long long im = ~am;
             uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
             uint32_t base = 0;
@@ -149,23 +221,15 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, uint32_t cap, cons
         if (am == 0) break;
         if (active) {
             while (rt_is_inner(tv.cur)) {
-                if (STATS) { unsigned long long ex = __ballot(true); if ((int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1) dbg[3]++; }
+                if (STATS) { unsigned long long ex = __ballot(true); if ((int)lane == __ffsll((long long)ex) - 1) dbg[2]++; }
                 rt_node_step<STATS>(nodes, tv, RT_TMIN, hit, stk, &cnt);
             }
             if (tv.cur >= 0) {
                 if (tv.cur != RT_EMPTY_STACK) rt_sentinel_step(wo, wd, tv, stk);
             } else {
                 do {
-                    if (STATS) {
-                        unsigned long long ex = __ballot(true);
-                        uint32_t x = ~(uint32_t)tv.cur;
-                        int kind = (x & RT_LEAF_INSTANCE_BIT) ? 4 : (int)((x >> 28) & 3u);
-                        bool first = (int)(threadIdx.x & 63) == __ffsll((long long)ex) - 1;
-                        if (first) dbg[4]++;
-                        for (int k = 0; k < 5; ++k) { unsigned long long bk = __ballot(kind == k); if (first && bk) dbg[5 + k]++; }
-                        dbg[10]++;
-                    }
-                    rt_leaf_step<STATS>(sc, wo, wd, time, RT_TMIN, src, tv, hit, stk, &cnt);
+                    if (STATS) { unsigned long long ex = __ballot(true); if ((int)lane == __ffsll((long long)ex) - 1) dbg[3]++; }
+                    rt_leaf_step<STATS>(prims, wo, wd, time, RT_TMIN, src, tv, hit, stk, &cnt);
                 } while (tv.cur < 0);
             }
             if (tv.cur == RT_EMPTY_STACK) {
@@ -178,7 +242,7 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, uint32_t cap, cons
         atomicAdd(work + 0, (unsigned long long)cnt.nodes); atomicAdd(work + 1, (unsigned long long)cnt.spheres);
         atomicAdd(work + 2, (unsigned long long)cnt.mspheres); atomicAdd(work + 3, (unsigned long long)cnt.rects);
         atomicAdd(work + 4, (unsigned long long)cnt.instances); atomicAdd(work + 7, (unsigned long long)cnt.boxes);
-        for (int k = 0; k < 12; ++k) if (dbg[k]) atomicAdd(work + 16 + k, (unsigned long long)dbg[k]);
+        for (int k = 0; k < 4; ++k) if (dbg[k]) atomicAdd(work + 16 + k, (unsigned long long)dbg[k]);
     }
 }
 
@@ -343,60 +407,99 @@ struct RtScene {
     size_t ws_paths = 0, ws_cap = 0;   // paths the workspace was sized for; slots per queue region
     rt_f4 *qa[2] = {nullptr, nullptr}, *qb[2] = {nullptr, nullptr}, *qc[2] = {nullptr, nullptr}, *contrib = nullptr, *hits = nullptr;
     uint32_t* counts = nullptr;            // [bounce][region] queue sizes, then [bounce][region] trace cursors
-    int lds_nodes = 0, lds_bytes = 0;      // k_trace: nodes cached in LDS and its dynamic LDS size
+    RtTracePlan plan;                      // k_trace: what lives in the block's LDS
+    int lds_bytes = 0;                     // k_trace: dynamic LDS size
+    unsigned trace_gx = 1;                 // k_trace: blocks per region
     unsigned long long* work = nullptr;   // 16 work counters of the instrumented kernel
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> ev_trace;      // per-bounce event pairs around k_trace (RT_FLAG_TIME_TRACE)
-    int lds_stack = 1;                     // stack entries per ray in k_trace
-    int refill_lanes = 16;                 // idle lanes of a wave that trigger a refill in k_trace
-    int trace_blocks_per_cu = 4;           // resident k_trace blocks per CU (0 = as many as the LDS allows); more thrash the 32 KB L1
-    int trace_block = 256;                 // threads per k_trace block (256 or 1024)
+    int trace_block = 1024;                // threads per k_trace block (1024, or 256 where a block cannot have 160 KB of LDS)
 };
 
-// k_trace comes in two block shapes: 1024 threads (one block per CU, its 16 waves share one LDS copy of the node array)
-// and 256 threads (several blocks per CU, each with a small copy of the top of the tree).
-static void launch_trace(RtScene* s, bool stats, dim3 grid, hipStream_t st, uint32_t cap, const uint32_t* cin, uint32_t* cursors,
+// k_trace comes in two block shapes: 1024 threads (one block per CU; its 16 waves share one LDS copy of the scene) and,
+// where a workgroup cannot have that much LDS, 256 threads (four blocks per CU, each with a 40 KB plan).
+static void launch_trace(RtScene* s, bool stats, hipStream_t st, uint32_t cap, const uint32_t* cin, uint32_t* cursors,
                          const rt_f4* qa, const rt_f4* qb) {
-#define RT_LAUNCH_TRACE(STATS_, TB_)                                                                                         \
-    hipLaunchKernelGGL((k_trace<STATS_, TB_>), grid, dim3(TB_), (size_t)s->lds_bytes, st, s->view, cap, cin, cursors, qa, qb, \
-                       s->hits, s->lds_nodes, s->lds_stack, s->refill_lanes, s->work)
-    if (s->trace_block == 1024) { if (stats) RT_LAUNCH_TRACE(true, 1024); else RT_LAUNCH_TRACE(false, 1024); }
-    else { if (stats) RT_LAUNCH_TRACE(true, 256); else RT_LAUNCH_TRACE(false, 256); }
+    dim3 grid(s->trace_gx, RT_SHARDS);
+#define RT_LAUNCH_TRACE(TB_, WIDE_, RES_)                                                                                     \
+    do {                                                                                                                      \
+        if (stats) hipLaunchKernelGGL((k_trace<true, TB_, WIDE_, RES_>), grid, dim3(TB_), (size_t)s->lds_bytes, st, s->view, s->plan, cap, \
+                                      cin, cursors, qa, qb, s->hits, s->work);                                                \
+        else hipLaunchKernelGGL((k_trace<false, TB_, WIDE_, RES_>), grid, dim3(TB_), (size_t)s->lds_bytes, st, s->view, s->plan, cap,      \
+                                cin, cursors, qa, qb, s->hits, s->work);                                                      \
+    } while (0)
+    if (s->trace_block == 1024 && s->plan.resident) RT_LAUNCH_TRACE(1024, false, true);
+    else if (s->trace_block == 1024 && !s->plan.wide_stack) RT_LAUNCH_TRACE(1024, false, false);
+    else if (s->trace_block == 1024) RT_LAUNCH_TRACE(1024, true, false);
+    else RT_LAUNCH_TRACE(256, true, false);
 #undef RT_LAUNCH_TRACE
 }
 
-// Chooses k_trace's block shape and LDS plan for a scene.  LDS per block = [cached nodes][stack entries x threads].
+// Fills the LDS of a k_trace block of `threads` threads within `budget` bytes.  The stack always has the full depth the
+// BVH can need.  If the whole node array fits beside a stack of 16-bit entries (and node indices fit 15 bits), that form
+// is used and the room left goes to whole primitive arrays; otherwise 32-bit entries and a breadth-first node prefix.
+static void fill_plan(const RtSceneView& v, int max_stack, int threads, int budget, int refill_lanes, bool allow_narrow, RtTracePlan& pl,
+                      int& lds_bytes) {
+    const int stack_cap = std::max(1, max_stack);
+    pl.stack_cap = stack_cap; pl.refill_lanes = refill_lanes; pl.resident = 0;
+    pl.off_spheres = pl.off_mspheres = pl.off_rects = pl.off_boxes = pl.off_instances = -1;
+    const int narrow = stack_cap * threads * 2, wide = stack_cap * threads * 4;
+    int used;
+    if (allow_narrow && v.n_nodes > 0 && v.n_nodes <= 32767 && v.n_nodes * 64 + narrow <= budget) {
+        pl.wide_stack = 0; pl.n_nodes_lds = v.n_nodes;
+        used = v.n_nodes * 64;
+        int room = budget - used - narrow;
+        auto place = [&](int n_records, int32_t& off) {
+            if (n_records > 0 && n_records * 16 <= room) { off = used / 16; used += n_records * 16; room -= n_records * 16; }
+        };
+        place(v.n_spheres, pl.off_spheres);
+        place(v.n_boxes * 2, pl.off_boxes);
+        place(v.n_instances * 2, pl.off_instances);
+        place(v.n_rects * 2, pl.off_rects);
+        place(v.n_mspheres * 3, pl.off_mspheres);
+        pl.resident = (v.n_spheres == 0 || pl.off_spheres >= 0) && (v.n_boxes == 0 || pl.off_boxes >= 0) &&
+                      (v.n_instances == 0 || pl.off_instances >= 0) && (v.n_rects == 0 || pl.off_rects >= 0) &&
+                      (v.n_mspheres == 0 || pl.off_mspheres >= 0);
+        pl.off_stack = used / 16;
+        lds_bytes = used + narrow;
+    } else {
+        pl.wide_stack = 1;
+        pl.n_nodes_lds = std::max(0, std::min(v.n_nodes, (budget - wide) / 64));
+        used = pl.n_nodes_lds * 64;
+        pl.off_stack = used / 16;
+        lds_bytes = used + wide;
+    }
+}
+
+// Chooses k_trace's block shape, LDS plan and grid for a scene.
 static int plan_trace(RtScene* s) {
-    const int n_nodes = s->view.n_nodes;
-    const int stack = std::max(1, s->flat.max_stack);
-    const int lds_cu = 160 * 1024;
-    s->lds_stack = stack;
+    int refill = 16;
+    if (const char* e = std::getenv("RT_REFILL_LANES")) refill = std::max(1, std::min(64, std::atoi(e)));
     const char* env_tb = std::getenv("RT_TRACE_BLOCK");
-    int want = env_tb ? std::atoi(env_tb) : 1024;
-    const int big_stack = stack * 1024 * (int)sizeof(int);
-    if (want == 1024 && big_stack + 64 <= lds_cu - 1024) {
-        int room = (lds_cu - 1024 - big_stack) / 64;
-        s->trace_block = 1024;
-        s->lds_nodes = std::max(0, std::min(n_nodes, room));
-        s->lds_bytes = big_stack + s->lds_nodes * 64;
-        s->trace_blocks_per_cu = 1;
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
-        if (e1 == hipSuccess && e2 == hipSuccess) return RT_OK;
-        (void)hipGetLastError();   // this device does not give one block that much LDS: use the small blocks
+    const int want = env_tb ? std::atoi(env_tb) : 1024;
+    const char* env_w = std::getenv("RT_TRACE_WIDE_STACK"); const bool narrow_ok = !(env_w && std::atoi(env_w) != 0);
+    int blocks_per_cu = 1;
+    bool planned = false;
+    if (want == 1024 && s->flat.max_stack * 1024 * 4 + 64 <= 160 * 1024 - 512) {
+        fill_plan(s->view, s->flat.max_stack, 1024, 160 * 1024 - 512, refill, narrow_ok, s->plan, s->lds_bytes);
+        const void* fns[2];
+        if (s->plan.resident) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, false, true>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, false, true>); }
+        else if (!s->plan.wide_stack) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, false, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, false, false>); }
+        else { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, false>); }
+        hipError_t e = hipFuncSetAttribute(fns[0], hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute(fns[1], hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
+        if (e == hipSuccess) { s->trace_block = 1024; planned = true; }
+        else (void)hipGetLastError();   // this device does not give one workgroup that much LDS: use the small blocks
     }
-    const char* env = std::getenv("RT_LDS_BUDGET_KB");
-    int budget = (env ? std::max(4, std::min(64, std::atoi(env))) : 40) * 1024;
-    int stack_bytes = stack * 256 * (int)sizeof(int);
-    s->trace_block = 256;
-    s->lds_nodes = std::max(0, std::min(n_nodes, (budget - stack_bytes) / 64));
-    s->lds_bytes = stack_bytes + s->lds_nodes * 64;
-    s->trace_blocks_per_cu = 4;
-    if (const char* e3 = std::getenv("RT_TRACE_BLOCKS_PER_CU")) s->trace_blocks_per_cu = std::max(0, std::min(8, std::atoi(e3)));
-    if (s->lds_bytes > 48 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+    if (!planned) {
+        fill_plan(s->view, s->flat.max_stack, 256, 40 * 1024 - 128, refill, false, s->plan, s->lds_bytes);
+        s->trace_block = 256; blocks_per_cu = 4;
+        if (s->lds_bytes > 48 * 1024) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, 256, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, 256, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+        }
     }
+    s->trace_gx = (unsigned)std::max(1, (std::max(1, s->n_cu) * blocks_per_cu + RT_SHARDS - 1) / RT_SHARDS);
     return RT_OK;
 }
 
@@ -515,7 +618,6 @@ int rt_scene_create(const RtBuilder* b, RtObj world, int device, RtScene** out) 
         if ((r = upload(s, f.boxes, &v.boxes))) return r;
         s->view = v;
         if ((r = plan_trace(s))) return r;
-        if (const char* e2 = std::getenv("RT_REFILL_LANES")) s->refill_lanes = std::max(1, std::min(64, std::atoi(e2)));
         return RT_OK;
     }();
     if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
@@ -588,10 +690,6 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     if (time_trace) {
         while ((int)s->ev_trace.size() < 2 * p->max_depth) { hipEvent_t e = nullptr; HIP_TRY(hipEventCreate(&e)); s->ev_trace.push_back(e); }
     }
-    // k_trace: persistent grid, as many blocks as stay resident (LDS-limited), split over the regions
-    const int lds_limit = std::max(1, std::min(8, (160 * 1024) / std::max(1, s->lds_bytes)));
-    const int blocks_per_cu = s->trace_blocks_per_cu > 0 ? std::min(s->trace_blocks_per_cu, lds_limit) : lds_limit;
-    dim3 tgrid((unsigned)std::max(1, (std::max(1, s->n_cu) * blocks_per_cu + RT_SHARDS - 1) / RT_SHARDS), RT_SHARDS);
     if (instrumented) HIP_TRY(hipMemsetAsync(s->work, 0, 32 * sizeof(unsigned long long), st));
 
     for (int done = 0; done < p->spp;) {
@@ -615,7 +713,7 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
             uint32_t* cout = s->counts + (size_t)(b + 1) * RT_SHARDS * RT_COUNT_STRIDE;
             uint32_t* cursors = s->counts + (size_t)(RT_MAX_BOUNCES + 2 + b) * RT_SHARDS * RT_COUNT_STRIDE;
             if (time_trace) HIP_TRY(hipEventRecord(s->ev_trace[2 * (b - 1)], st));
-            launch_trace(s, instrumented, tgrid, st, cap, cin, cursors, s->qa[in], s->qb[in]);
+            launch_trace(s, instrumented, st, cap, cin, cursors, s->qa[in], s->qb[in]);
             if (time_trace) HIP_TRY(hipEventRecord(s->ev_trace[2 * (b - 1) + 1], st));
             if (instrumented)
                 hipLaunchKernelGGL(k_shade<true>, bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, cin, cout, s->qa[in], s->qb[in], s->qc[in], s->hits,
@@ -657,9 +755,8 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         if (std::getenv("RT_DEBUG_WORK")) {
             unsigned long long w2[16];
             HIP_TRY(hipMemcpy(w2, s->work + 16, sizeof(w2), hipMemcpyDeviceToHost));
-            std::fprintf(stderr, "k_trace wave counters: outer %llu (active lanes %llu) refills %llu node-iters %llu leaf-iters %llu "
-                         "[sphere %llu msphere %llu rect %llu box %llu inst %llu] leaf lane-iters %llu | lane node-steps %llu\n",
-                         w2[0], w2[1], w2[2], w2[3], w2[4], w2[5], w2[6], w2[7], w2[8], w2[9], w2[10], w[0]);
+            std::fprintf(stderr, "k_trace wave counters: outer %llu refills %llu node-iters %llu leaf-iters %llu | lane node-steps %llu\n",
+                         w2[0], w2[1], w2[2], w2[3], w[0]);
         }
     }
     local.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();

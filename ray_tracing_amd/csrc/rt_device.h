@@ -278,7 +278,7 @@ struct RtCounters { uint32_t nodes, spheres, mspheres, rects, instances, boxes; 
 //
 // The traversal is written as three steps on an explicit state so that the plain per-ray loop below and the
 // persistent kernel (which refills finished lanes with new rays between steps) share them.
-//   Stack : set(i, v) / get(i) on an int array of cap() entries.      Nodes : get(node, q[4]) fetches the 64-byte node record.
+//   Stack : see rt_pop.      Nodes : get(node, q[4]) fetches the 64-byte node record.      Prims : see RtGlobalPrims.
 struct RtTrav { v3 o, d, inv; int32_t inst, sp, cur; };
 RT_HD void rt_trav_ray(RtTrav& tv, v3 o, v3 d) {
     tv.o = o; tv.d = d; tv.inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
@@ -292,20 +292,39 @@ struct RtGlobalNodes {
     }
 };
 
+// Primitive records as the leaf step fetches them.  This one reads the scene's global arrays; the closest-hit kernel
+// has its own that serves arrays resident in LDS.
+struct RtGlobalPrims {
+    const RtSceneView* sc;
+    RT_HDM rt_f4 sphere(uint32_t i) const { return ld4(sc->spheres + i); }
+    RT_HDM void msphere(uint32_t i, rt_f4& m0, rt_f4& m1, rt_f4& m2) const {
+        const rt_f4* m = sc->mspheres + 3 * (size_t)i; m0 = ld4(m); m1 = ld4(m + 1); m2 = ld4(m + 2);
+    }
+    RT_HDM void rect(uint32_t i, rt_f4& r0, rt_f4& r1) const { r0 = ld4(sc->rects + 2 * (size_t)i); r1 = ld4(sc->rects + 2 * (size_t)i + 1); }
+    RT_HDM void box(uint32_t i, rt_f4& b0, rt_f4& b1) const { b0 = ld4(sc->boxes + 2 * (size_t)i); b1 = ld4(sc->boxes + 2 * (size_t)i + 1); }
+    RT_HDM void instance(uint32_t i, rt_f4& i0, rt_f4& i1) const {
+        i0 = ld4(sc->instances + 2 * (size_t)i); i1 = ld4(sc->instances + 2 * (size_t)i + 1);
+    }
+};
+
 RT_HD bool rt_is_inner(int32_t cur) { return (uint32_t)cur < (uint32_t)RT_SENTINEL; }
 
 RT_HD void rt_trav_begin(const RtSceneView& sc, v3 wo, v3 wd, RtTrav& tv) {
     rt_trav_ray(tv, wo, wd);
     tv.inst = -1; tv.sp = 0; tv.cur = sc.root < 0 ? RT_EMPTY_STACK : sc.root;
 }
+// A Stack holds the postponed children of one ray.  put(i, node, which, code): entry i = child `which` (0 left, 1 right) of
+// inner node `node`, whose child code is `code` (a stack may keep either form); put_sentinel(i); take(i) returns the
+// child code or RT_SENTINEL; cap() = entries available.
 template <class Stack>
-RT_HD int32_t rt_pop(RtTrav& tv, Stack& stk) { return tv.sp > 0 ? stk.get(--tv.sp) : RT_EMPTY_STACK; }
+RT_HD int32_t rt_pop(RtTrav& tv, Stack& stk) { return tv.sp > 0 ? stk.take(--tv.sp) : RT_EMPTY_STACK; }
 
 // tv.cur is an inner node: test both child boxes, descend into the nearer hit child, push the farther one.
 template <bool STATS, class Nodes, class Stack>
 RT_HD void rt_node_step(const Nodes& nodes, RtTrav& tv, float tmin, const RtHit& hit, Stack& stk, RtCounters* wc) {
     rt_f4 q[4];
-    nodes.get(tv.cur, q);
+    const int32_t node = tv.cur;
+    nodes.get(node, q);
     if (STATS) wc->nodes++;
     float tl = rt_slab(q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, tv.o, tv.inv, tmin, hit.t);
     float tr = rt_slab(q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, tv.o, tv.inv, tmin, hit.t);
@@ -313,7 +332,7 @@ RT_HD void rt_node_step(const Nodes& nodes, RtTrav& tv, float tmin, const RtHit&
     bool hl = tl < rt_inf(), hr = tr < rt_inf();
     if (hl && hr) {
         bool left_first = tl <= tr;
-        if (tv.sp < stk.cap()) stk.set(tv.sp++, left_first ? cr : cl);
+        if (tv.sp < stk.cap()) stk.put(tv.sp++, node, left_first ? 1 : 0, left_first ? cr : cl);
         tv.cur = left_first ? cl : cr;
     } else if (hl) tv.cur = cl;
     else if (hr) tv.cur = cr;
@@ -328,14 +347,15 @@ RT_HD void rt_sentinel_step(v3 wo, v3 wd, RtTrav& tv, Stack& stk) {
 }
 
 // tv.cur is a leaf code (< 0): enter the instance, or intersect the leaf's primitives; then pop.
-template <bool STATS, class Stack>
-RT_HD void rt_leaf_step(const RtSceneView& sc, v3 wo, v3 wd, float time, float tmin, uint32_t src, RtTrav& tv, RtHit& hit,
+template <bool STATS, class Prims, class Stack>
+RT_HD void rt_leaf_step(const Prims& prims, v3 wo, v3 wd, float time, float tmin, uint32_t src, RtTrav& tv, RtHit& hit,
                         Stack& stk, RtCounters* wc) {
     uint32_t x = ~(uint32_t)tv.cur;
     if (x & RT_LEAF_INSTANCE_BIT) {
         int32_t ii = (int32_t)(x & 0x3FFFFFFFu);
-        rt_f4 i0 = ld4(sc.instances + 2 * (size_t)ii), i1 = ld4(sc.instances + 2 * (size_t)ii + 1);
-        if (tv.sp < stk.cap()) stk.set(tv.sp++, RT_SENTINEL);
+        rt_f4 i0, i1;
+        prims.instance((uint32_t)ii, i0, i1);
+        if (tv.sp < stk.cap()) stk.put_sentinel(tv.sp++);
         tv.inst = ii;
         if (STATS) wc->instances++;
         rt_trav_ray(tv, rt_to_object_point(i0, i1, wo), rt_to_object_dir(i0, wd));
@@ -348,24 +368,26 @@ RT_HD void rt_leaf_step(const RtSceneView& sc, v3 wo, v3 wd, float time, float t
         float t;
         if (kind == RT_KIND_BOX) {
             if (STATS) wc->boxes++;
-            rt_f4 b0 = ld4(sc.boxes + 2 * (size_t)idx), b1 = ld4(sc.boxes + 2 * (size_t)idx + 1);
+            rt_f4 b0, b1;
+            prims.box(idx, b0, b1);
             int skip = (src >> 3) == (RT_HIT_CODE(RT_KIND_BOX, idx << 3) >> 3) ? (int)(src & 7u) : -1, face = 0;
             t = rt_hit_box(b0, b1, tv.o, tv.d, tmin, hit.t, skip, face);
             code = RT_HIT_CODE(RT_KIND_BOX, (idx << 3) | (uint32_t)face);
         } else if (kind == RT_KIND_RECT) {
             if (STATS) wc->rects++;
             if (code == src) continue;
-            rt_f4 r0 = ld4(sc.rects + 2 * (size_t)idx), r1 = ld4(sc.rects + 2 * (size_t)idx + 1);
+            rt_f4 r0, r1;
+            prims.rect(idx, r0, r1);
             t = rt_hit_rect(r0, r1.x, f2i(r1.y), tv.o, tv.d, tmin, hit.t);
         } else {  // sphere or moving sphere: one intersection path, the centre is the only difference
             v3 c; float r;
             if (kind == RT_KIND_SPHERE) {
-                rt_f4 sp = ld4(sc.spheres + idx);
+                rt_f4 sp = prims.sphere(idx);
                 c = mk3(sp.x, sp.y, sp.z); r = sp.w;
                 if (STATS) wc->spheres++;
             } else {
-                const rt_f4* m = sc.mspheres + 3 * (size_t)idx;
-                rt_f4 m0 = ld4(m), m1 = ld4(m + 1), m2 = ld4(m + 2);
+                rt_f4 m0, m1, m2;
+                prims.msphere(idx, m0, m1, m2);
                 c = rt_msphere_center(m0, m1, m2, time); r = m0.w;
                 if (STATS) wc->mspheres++;
             }
@@ -385,13 +407,14 @@ RT_HD void rt_closest_hit(const RtSceneView& sc, v3 wo, v3 wd, float time, float
     RtTrav tv;
     rt_trav_begin(sc, wo, wd, tv);
     RtGlobalNodes nodes; nodes.nodes = sc.nodes;
+    RtGlobalPrims prims; prims.sc = &sc;
     while (tv.cur != RT_EMPTY_STACK) {
         while (rt_is_inner(tv.cur)) rt_node_step<STATS>(nodes, tv, tmin, hit, stk, wc);
         if (tv.cur >= 0) {
             if (tv.cur != RT_EMPTY_STACK) rt_sentinel_step(wo, wd, tv, stk);
             continue;
         }
-        do rt_leaf_step<STATS>(sc, wo, wd, time, tmin, src, tv, hit, stk, wc); while (tv.cur < 0);
+        do rt_leaf_step<STATS>(prims, wo, wd, time, tmin, src, tv, hit, stk, wc); while (tv.cur < 0);
     }
 }
 

@@ -10,7 +10,13 @@
 #include "../../ray_tracing_amd/csrc/rt_device.h"
 #include "../../ray_tracing_amd/csrc/scene_builder.h"
 
-struct ArrStack { int v[RT_STACK_DEPTH]; void set(int i, int x) { v[i] = x; } int get(int i) const { return v[i]; } int cap() const { return RT_STACK_DEPTH; } };
+struct ArrStack {
+    int v[RT_STACK_DEPTH];
+    void put(int i, int, int, int code) { v[i] = code; }
+    void put_sentinel(int i) { v[i] = RT_SENTINEL; }
+    int take(int i) const { return v[i]; }
+    int cap() const { return RT_STACK_DEPTH; }
+};
 
 static void make_cam(const RtCamera* cam, RtCameraDev& cd) {
     rt::CameraDesc d;
