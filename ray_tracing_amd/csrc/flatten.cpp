@@ -260,6 +260,17 @@ private:
         out.media.push_back(f4(i2f(inst), i2f(first[0]), i2f(count[0]), i2f(first[1])));
         out.media.push_back(f4(i2f(count[1]), i2f(first[2]), i2f(count[2]), i2f(o.id)));
         out.media.push_back(f4(i2f(first[3]), i2f(count[3]), 0, 0));
+        // A boundary that is one sphere or one box (every shipped scene) is repeated inline, with its instance transform,
+        // so that the medium test needs this one record and no dependent fetches.
+        int fast = 0;
+        rt_f4 p0 = f4(0, 0, 0, 0), p1 = f4(0, 0, 0, 0), i0 = f4(1, 0, 0, 0), i1 = f4(0, 0, 0, 0);
+        if (count[0] + count[1] + count[2] + count[3] == 1) {
+            if (count[0] == 1) { fast = 1; p0 = out.spheres[first[0]]; }
+            else if (count[3] == 1) { fast = 2; p0 = out.boxes[2 * (size_t)first[3]]; p1 = out.boxes[2 * (size_t)first[3] + 1]; }
+        }
+        if (inst >= 0) { i0 = out.instances[2 * (size_t)inst]; i1 = out.instances[2 * (size_t)inst + 1]; }
+        out.media.push_back(f4(i2f(fast), i2f(inst >= 0 ? 1 : 0), 0, 0));
+        out.media.push_back(p0); out.media.push_back(p1); out.media.push_back(i0); out.media.push_back(i1);
         return true;
     }
     void emit_tables() {

@@ -246,6 +246,14 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, 
     }
 }
 
+#define RT_SHADE_MEDIA_LDS 8
+struct ShadeMedia {   // medium records: the first RT_SHADE_MEDIA_LDS media from the block's LDS copy
+    const rt_f4* global; lds_f4* lds;
+    __device__ __forceinline__ rt_f4 get(int m, int k) const {
+        return m < RT_SHADE_MEDIA_LDS ? lds_ld4(lds + RT_MEDIUM_F4 * m + k) : ld4(global + RT_MEDIUM_F4 * (size_t)m + k);
+    }
+};
+
 // Stage 2 of a bounce: media (mediums.rs:39-87), hit record, emission and scatter (lib.rs:64-71) for every ray of the
 // input queue, and the append of the scattered ray to the output queue through one wave-aggregated atomic
 // (ranks from ballot + mbcnt).  STATS = true also counts shades per material kind into `work` (16 x u64).
@@ -255,11 +263,26 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev f
                                                     const rt_f4* hits, rt_f4* oa, rt_f4* ob, rt_f4* oc, rt_f4* contrib,
                                                     unsigned long long* work) {
     const uint32_t n = counts_in[blockIdx.y * RT_COUNT_STRIDE];
+    if (blockIdx.x * RT_BLOCK >= n) return;
+    // the medium records are the same for every ray: one LDS copy per block instead of a chain of fetches per ray
+    __shared__ __align__(16) rt_f4 s_media[RT_SHADE_MEDIA_LDS * RT_MEDIUM_F4];
+    for (int i = threadIdx.x; i < min(sc.n_media, RT_SHADE_MEDIA_LDS) * RT_MEDIUM_F4; i += RT_BLOCK) s_media[i] = ld4(sc.media + i);
+    __syncthreads();
+    ShadeMedia msrc; msrc.global = sc.media; msrc.lds = (lds_f4*)s_media;
     const uint32_t out_shard = (blockIdx.x + blockIdx.y) % RT_SHARDS;
     uint32_t* n_out_ptr = counts_out + out_shard * RT_COUNT_STRIDE;
     ia += (size_t)blockIdx.y * cap; ib += (size_t)blockIdx.y * cap; ic += (size_t)blockIdx.y * cap; hits += (size_t)blockIdx.y * cap;
     oa += (size_t)out_shard * cap; ob += (size_t)out_shard * cap; oc += (size_t)out_shard * cap;
+#ifdef RT_SHADE_CLOCK   /* variant builds only: wave clocks per section of the loop body, summed into work[20..27] */
+    unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev;
+#define RT_TICK(k_) do { unsigned long long t_ = __builtin_readcyclecounter(); clk[k_] += t_ - t_prev; t_prev = t_; } while (0)
+#else
+#define RT_TICK(k_) do { } while (0)
+#endif
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
+#ifdef RT_SHADE_CLOCK
+        t_prev = __builtin_readcyclecounter();
+#endif
         uint32_t i = base + threadIdx.x;
         bool alive = false;
         rt_f4 na, nb, nc;
@@ -274,10 +297,23 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev f
             sample += (uint32_t)fr.sample_base;
             uint32_t rnd[4];
             rt_philox(pixel, sample, (uint32_t)bounce, 0u, fr.key0, fr.key1, rnd);
+#ifdef RT_SHADE_CLOCK
+            asm volatile("" ::"v"(a.x), "v"(b.x), "v"(c.x), "v"(h.x));   // the loads have landed before the clock is read
+#endif
+            RT_TICK(0);
 
             RtHit hit; hit.t = h.x; hit.code = (uint32_t)f2i(h.y); hit.inst = f2i(h.z);
-            if (sc.n_media > 0) rt_media_hits(sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, rnd, hit);
+#ifdef RT_MEDIA_TWICE   /* timing experiment: the media test run twice with the same result */
+            if (sc.n_media > 0) {
+                RtHit h2 = hit;
+                rt_media_hits(sc, msrc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, rnd, h2);
+                asm volatile("" : "+v"(o.x), "+v"(d.x), "+v"(h2.t));
+                if (h2.t < 0.0f) hit.t = h2.t;   // never true; keeps the first call alive
+            }
+#endif
+            if (sc.n_media > 0) rt_media_hits(sc, msrc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, rnd, hit);
             if (STATS) { atomicAdd(work + 5, (unsigned long long)sc.n_media); if (hit.code == RT_HIT_NONE) atomicAdd(work + 6, 1ull); }
+            RT_TICK(1);
 
             v3 add = mk3(0, 0, 0);
             if (hit.code == RT_HIT_NONE) {
@@ -285,8 +321,19 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev f
             } else {
                 RtSurface sf;
                 rt_surface(sc, o, d, time, hit, false, sf);
+                RT_TICK(2);
                 v3 atten, dir, emitted;
+#ifdef RT_SCATTER_TWICE   /* timing experiment */
+                {
+                    RtSurface sf2; v3 at2, dir2, em2;
+                    rt_surface(sc, o, d, time, hit, false, sf2);
+                    bool s2 = rt_scatter(sc, sf2, d, rt_u24(rnd[0]), rt_u24(rnd[1]), at2, dir2, em2);
+                    asm volatile("" : "+v"(o.x), "+v"(d.x), "+v"(at2.x), "+v"(dir2.x), "+v"(em2.x));
+                    if (s2 && at2.x < -1.0f) beta.x = dir2.x + em2.x;   // never true
+                }
+#endif
                 bool scattered = rt_scatter(sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), atten, dir, emitted);
+                RT_TICK(3);
                 if (STATS) {
                     rt_f4 a0 = ld4(sc.materials + 2 * (size_t)sf.mat);
                     int mtype = f2i(a0.x), mtex = f2i(a0.y);
@@ -307,11 +354,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev f
                 }
             }
             if (add.x != 0.0f || add.y != 0.0f || add.z != 0.0f) {
+                // Light reaches a path where it ends (an emitter does not scatter, a miss has no next segment), so the
+                // path's slot, zeroed before the pass, is written exactly once; only a surface that both emits and
+                // scatters would have to add to an earlier value.
                 float4* cp = reinterpret_cast<float4*>(contrib + pid);
-                float4 cv = *cp;
-                cv.x += add.x; cv.y += add.y; cv.z += add.z;
+                float4 cv = make_float4(add.x, add.y, add.z, 0.0f);
+                if (alive) { float4 old = *cp; cv.x += old.x; cv.y += old.y; cv.z += old.z; }
                 *cp = cv;
             }
+            RT_TICK(4);
         }
         // wave-aggregated append: one atomic per wave, slot = base + rank among the live lanes
         unsigned long long mask = __ballot(alive);
@@ -327,7 +378,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev f
                 *reinterpret_cast<float4*>(oc + slot) = make_float4(nc.x, nc.y, nc.z, nc.w);
             }
         }
+        RT_TICK(5);
     }
+#ifdef RT_SHADE_CLOCK
+    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 8; ++k) if (clk[k]) atomicAdd(work + 20 + k, clk[k]);
+#endif
+#undef RT_TICK
 }
 
 // accum[pixel] += sum over the pass's samples, in sample order (main.rs:585-589).
@@ -690,7 +746,8 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     if (time_trace) {
         while ((int)s->ev_trace.size() < 2 * p->max_depth) { hipEvent_t e = nullptr; HIP_TRY(hipEventCreate(&e)); s->ev_trace.push_back(e); }
     }
-    if (instrumented) HIP_TRY(hipMemsetAsync(s->work, 0, 32 * sizeof(unsigned long long), st));
+    const bool debug_work = std::getenv("RT_DEBUG_WORK") != nullptr;
+    if (instrumented || debug_work) HIP_TRY(hipMemsetAsync(s->work, 0, 32 * sizeof(unsigned long long), st));
 
     for (int done = 0; done < p->spp;) {
         int chunk = std::min(chunk_max, p->spp - done);
@@ -752,12 +809,13 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         unsigned long long w[16];
         HIP_TRY(hipMemcpy(w, s->work, sizeof(w), hipMemcpyDeviceToHost));
         for (int i = 0; i < 16; ++i) local.work[i] = w[i];
-        if (std::getenv("RT_DEBUG_WORK")) {
-            unsigned long long w2[16];
-            HIP_TRY(hipMemcpy(w2, s->work + 16, sizeof(w2), hipMemcpyDeviceToHost));
-            std::fprintf(stderr, "k_trace wave counters: outer %llu refills %llu node-iters %llu leaf-iters %llu | lane node-steps %llu\n",
-                         w2[0], w2[1], w2[2], w2[3], w[0]);
-        }
+    }
+    if (debug_work) {   // developer output: wave-level counters of the instrumented k_trace, section clocks of a -DRT_SHADE_CLOCK build
+        unsigned long long w2[16];
+        HIP_TRY(hipMemcpy(w2, s->work + 16, sizeof(w2), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "k_shade wave clocks: load+philox %llu media %llu surface %llu scatter %llu contrib %llu append %llu\n",
+                     w2[4], w2[5], w2[6], w2[7], w2[8], w2[9]);
+        std::fprintf(stderr, "k_trace wave counters: outer %llu refills %llu node-iters %llu leaf-iters %llu\n", w2[0], w2[1], w2[2], w2[3]);
     }
     local.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     if (stats) *stats = local;

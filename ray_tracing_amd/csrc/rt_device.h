@@ -490,7 +490,14 @@ RT_HD void rt_boundary_pair(const RtSceneView& sc, rt_f4 m2, rt_f4 m3, rt_f4 m4,
 // the current closest hit replaces it.  With one fixed draw per (medium, segment) the outcome does
 // not depend on the order in which the reference's BVH would have visited the medium.
 // rnd0 = Philox block 0 of this bounce (its lanes 2, 3 are the draws of media 0, 1).
-RT_HD void rt_media_hits(const RtSceneView& sc, v3 wo, v3 wd, float time, float tmin, uint32_t pixel, uint32_t sample,
+// MediaSrc::get(m, k) = record k of medium m (this one reads global memory; the indices are wave-uniform, so these are
+// scalar loads).
+struct RtGlobalMedia {
+    const rt_f4* media;
+    RT_HDM rt_f4 get(int m, int k) const { return ld4(media + RT_MEDIUM_F4 * (size_t)m + k); }
+};
+template <class MediaSrc>
+RT_HD void rt_media_hits(const RtSceneView& sc, const MediaSrc& msrc, v3 wo, v3 wd, float time, float tmin, uint32_t pixel, uint32_t sample,
                          uint32_t bounce, uint32_t key0, uint32_t key1, const uint32_t rnd0[4], RtHit& hit) {
     uint32_t r0 = rnd0[0], r1 = rnd0[1], r2 = rnd0[2], r3 = rnd0[3];  // scalars: an indexed array would live in scratch
     float len = rt_sqrt(dot3(wd, wd));
@@ -502,24 +509,42 @@ RT_HD void rt_media_hits(const RtSceneView& sc, v3 wo, v3 wd, float time, float 
             rt_philox(pixel, sample, bounce, (uint32_t)(k >> 2), key0, key1, nr);
             r0 = nr[0]; r1 = nr[1]; r2 = nr[2]; r3 = nr[3];
         }
-        const rt_f4* md = sc.media + RT_MEDIUM_F4 * (size_t)m;
-        rt_f4 m0 = ld4(md), m1 = ld4(md + 1);
+        rt_f4 m0 = msrc.get(m, 0), m1 = msrc.get(m, 1);
         if (!(rt_slab(m0.x, m0.y, m0.z, m1.x, m1.y, m1.z, wo, winv, tmin, hit.t) < rt_inf())) continue;
-        rt_f4 m2 = ld4(md + 2), m3 = ld4(md + 3), m4 = ld4(md + 4);
+        rt_f4 m5 = msrc.get(m, 5);
+        const int fast = rt_uniform(f2i(m5.x));
         v3 o = wo, d = wd;
-        int ii = rt_uniform(f2i(m2.x));
-        if (ii >= 0) {
-            rt_f4 i0 = ld4(sc.instances + 2 * (size_t)ii), i1 = ld4(sc.instances + 2 * (size_t)ii + 1);
-            o = rt_to_object_point(i0, i1, wo); d = rt_to_object_dir(i0, wd);
-        }
         float t1, t2;
-        rt_boundary_pair(sc, m2, m3, m4, o, d, time, t1, t2);                           // mediums.rs:46-47
-        if (!(t1 < rt_inf())) continue;
-        // The re-query offset 0.0001 vanishes in fp32 once |t1| exceeds ~1000 (the r = 5000 fog), so it is widened
-        // to a few ulps of t1 when that is larger.
-        float t_next = t1 + fmaxf(0.0001f, 1e-6f * fabsf(t1));
-        if (t2 < t_next) t2 = rt_boundary_hit(sc, m2, m3, m4, o, d, time, t_next, rt_inf());
-        if (!(t2 < rt_inf())) continue;                                             // also false for NaN (no second crossing)
+        if (fast != 0) {
+            // the boundary is one convex primitive: its two crossings are the entry and the exit (mediums.rs:46-47)
+            if (rt_uniform(f2i(m5.y)) != 0) {
+                rt_f4 i0 = msrc.get(m, 8), i1 = msrc.get(m, 9);
+                o = rt_to_object_point(i0, i1, wo); d = rt_to_object_dir(i0, wd);
+            }
+            rt_f4 p0 = msrc.get(m, 6);
+            if (fast == 1) {
+                if (!rt_sphere_roots(mk3(p0.x, p0.y, p0.z), p0.w, o, d, t1, t2)) continue;
+            } else {
+                rt_f4 p1 = msrc.get(m, 7);
+                int f_in, f_out;
+                if (!rt_box_slabs(p0, p1, o, d, t1, t2, f_in, f_out)) continue;
+            }
+            if (t2 < t1 + fmaxf(0.0001f, 1e-6f * fabsf(t1))) continue;                  // coincident crossings: no second one
+        } else {
+            rt_f4 m2 = msrc.get(m, 2), m3 = msrc.get(m, 3), m4 = msrc.get(m, 4);
+            int ii = rt_uniform(f2i(m2.x));
+            if (ii >= 0) {
+                rt_f4 i0 = ld4(sc.instances + 2 * (size_t)ii), i1 = ld4(sc.instances + 2 * (size_t)ii + 1);
+                o = rt_to_object_point(i0, i1, wo); d = rt_to_object_dir(i0, wd);
+            }
+            rt_boundary_pair(sc, m2, m3, m4, o, d, time, t1, t2);                       // mediums.rs:46-47
+            if (!(t1 < rt_inf())) continue;
+            // The re-query offset 0.0001 vanishes in fp32 once |t1| exceeds ~1000 (the r = 5000 fog), so it is widened
+            // to a few ulps of t1 when that is larger.
+            float t_next = t1 + fmaxf(0.0001f, 1e-6f * fabsf(t1));
+            if (t2 < t_next) t2 = rt_boundary_hit(sc, m2, m3, m4, o, d, time, t_next, rt_inf());
+            if (!(t2 < rt_inf())) continue;                                         // also false for NaN (no second crossing)
+        }
         if (t1 < tmin) t1 = tmin;
         if (t2 > hit.t) t2 = hit.t;
         if (t1 >= t2) continue;
@@ -532,6 +557,11 @@ RT_HD void rt_media_hits(const RtSceneView& sc, v3 wo, v3 wd, float time, float 
         float t = t1 + hit_dist * rt_rcp(len);
         if (t < hit.t) { hit.t = t; hit.code = RT_HIT_CODE(RT_KIND_MEDIUM, (uint32_t)m); hit.inst = -1; }
     }
+}
+RT_HD void rt_media_hits(const RtSceneView& sc, v3 wo, v3 wd, float time, float tmin, uint32_t pixel, uint32_t sample,
+                         uint32_t bounce, uint32_t key0, uint32_t key1, const uint32_t rnd0[4], RtHit& hit) {
+    RtGlobalMedia g; g.media = sc.media;
+    rt_media_hits(sc, g, wo, wd, time, tmin, pixel, sample, bounce, key0, key1, rnd0, hit);
 }
 
 // ------------------------------------------------------------------ hit record (objects.rs:126-152)

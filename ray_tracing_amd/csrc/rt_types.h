@@ -54,12 +54,15 @@ static inline int32_t rt_leaf_instance(int index) { return ~(int32_t)(RT_LEAF_IN
 #define RT_INSTANCE_F4 2
 enum { RT_OP_TRANSLATE = 0, RT_OP_ROTATE_Y = 1 };
 
-// ---- constant medium (mediums.rs:14-21), 4 x f4:
+// ---- constant medium (mediums.rs:14-21), 10 x f4:
 //   m0 = (box.min xyz, -1/density)      m1 = (box.max xyz, material index as int)
 //   m2 = int (instance or -1, sphere first, sphere count, msphere first)
 //   m3 = int (msphere count, rect first, rect count, object id)
 //   m4 = int (box first, box count, 0, 0)
-#define RT_MEDIUM_F4 5
+//   m5 = int (fast kind: 0 = scan the ranges above, 1 = the boundary is the one sphere in m6, 2 = the one box in m6, m7;
+//             1 if m8, m9 hold the instance record of m2.x; 0; 0)
+//   m6, m7 = that primitive's record, m8, m9 = that instance's record
+#define RT_MEDIUM_F4 10
 
 // ---- material (materials.rs), 2 x f4:
 //   a0 = int/float (type, texture index or -1, fuzz, ir)     a1 = (rgb, 0): Metal albedo, or the colour of a

@@ -27,7 +27,7 @@ def arrays(flat):
         return np.ctypeslib.as_array((C.c_int32 * (2 * n)).from_address(ptrs[i])).reshape(-1, 2).copy()
     return dict(root=root, max_stack=max_stack, nodes=f4(0, 4 * n_nodes).reshape(-1, 16), spheres=f4(1, n_sph), sphere_meta=i2(2, n_sph),
                 mspheres=f4(3, 3 * n_msph).reshape(-1, 12), msphere_meta=i2(4, n_msph), rects=f4(5, 2 * n_rect).reshape(-1, 8),
-                rect_meta=i2(6, n_rect), instances=f4(7, 2 * n_inst).reshape(-1, 8), media=f4(9, 5 * n_media).reshape(-1, 20),
+                rect_meta=i2(6, n_rect), instances=f4(7, 2 * n_inst).reshape(-1, 8), media=f4(9, 10 * n_media).reshape(-1, 40),
                 boxes=f4(14, 2 * n_box).reshape(-1, 8))
 
 

@@ -1,2 +1,3 @@
 set -e
-for c in final_scene.yml cornell.yml; do bash tools/sweep.sh $c 64 RT_TRACE_WIDE_STACK "0"; RT_TRACE_WIDE_STACK=1 bash tools/sweep.sh $c 64 RT_REFILL_LANES "16";  bash tools/sweep.sh $c 64 RT_REFILL_LANES "8 24"; done
+timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread 2>&1 | tail -3
+for c in final_scene.yml cornell.yml; do bash tools/sweep.sh $c 64 RT_REFILL_LANES "16"; done
