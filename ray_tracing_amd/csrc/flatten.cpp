@@ -278,7 +278,18 @@ private:
             int tex = m.tex; const double* rgb = m.albedo;
             if (tex >= 0 && b.textures[tex].type == RT_TEX_SOLID) { rgb = b.textures[tex].rgb; tex = -1; }  // bake SolidColor
             out.materials.push_back(f4(i2f(m.type), i2f(tex), (float)m.fuzz, (float)m.ir));
-            out.materials.push_back(f4((float)rgb[0], (float)rgb[1], (float)rgb[2], 0));
+            // .w = 1 when evaluating the texture is costly (a Noise anywhere in its tree): the shade kernel postpones
+            // such hits and evaluates them together
+            bool costly = false;
+            if (tex >= 0 && (m.type == RT_MAT_LAMBERTIAN || m.type == RT_MAT_LIGHT || m.type == RT_MAT_ISOTROPIC)) {
+                std::vector<int> todo(1, tex);
+                for (size_t k = 0; k < todo.size() && k < 64; ++k) {
+                    const TexNode& t = b.textures[todo[k]];
+                    if (t.type == RT_TEX_NOISE) costly = true;
+                    if (t.type == RT_TEX_CHECKER) { todo.push_back(t.even); todo.push_back(t.odd); }
+                }
+            }
+            out.materials.push_back(f4((float)rgb[0], (float)rgb[1], (float)rgb[2], i2f(costly ? 1 : 0)));
         }
         for (const TexNode& t : b.textures) {
             if (t.type == RT_TEX_CHECKER) { out.textures.push_back(f4(i2f(t.type), i2f(t.even), i2f(t.odd), 0)); out.textures.push_back(f4(0, 0, 0, 0)); }

@@ -274,20 +274,19 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev f
     ia += (size_t)blockIdx.y * cap; ib += (size_t)blockIdx.y * cap; ic += (size_t)blockIdx.y * cap; hits += (size_t)blockIdx.y * cap;
     oa += (size_t)out_shard * cap; ob += (size_t)out_shard * cap; oc += (size_t)out_shard * cap;
 #ifdef RT_SHADE_CLOCK   /* variant builds only: wave clocks per section of the loop body, summed into work[20..27] */
-    unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev;
+    unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
 #define RT_TICK(k_) do { unsigned long long t_ = __builtin_readcyclecounter(); clk[k_] += t_ - t_prev; t_prev = t_; } while (0)
 #else
 #define RT_TICK(k_) do { } while (0)
 #endif
-    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
-#ifdef RT_SHADE_CLOCK
-        t_prev = __builtin_readcyclecounter();
-#endif
-        uint32_t i = base + threadIdx.x;
-        bool alive = false;
+
+    // One ray per lane.  Returns true when the hit was postponed (costly texture, `may_postpone`): nothing has been
+    // written for that ray then.  Called from wave-uniform control flow only (the append votes over the wave).
+    auto shade = [&](uint32_t i, bool valid, bool may_postpone) -> bool {
+        bool alive = false, postponed = false;
         rt_f4 na, nb, nc;
         na.x = na.y = na.z = na.w = nb.x = nb.y = nb.z = nb.w = nc.x = nc.y = nc.z = nc.w = 0.0f;
-        if (i < n) {
+        if (valid) {
             rt_f4 a = ld4(ia + i), b = ld4(ib + i), c = ld4(ic + i), h = ld4(hits + i);
             v3 o = mk3(a.x, a.y, a.z), d = mk3(b.x, b.y, b.z), beta = mk3(c.x, c.y, c.z);
             float time = a.w;
@@ -312,45 +311,49 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev f
             }
 #endif
             if (sc.n_media > 0) rt_media_hits(sc, msrc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, rnd, hit);
-            if (STATS) { atomicAdd(work + 5, (unsigned long long)sc.n_media); if (hit.code == RT_HIT_NONE) atomicAdd(work + 6, 1ull); }
             RT_TICK(1);
 
             v3 add = mk3(0, 0, 0);
             if (hit.code == RT_HIT_NONE) {
+                if (STATS) { atomicAdd(work + 5, (unsigned long long)sc.n_media); atomicAdd(work + 6, 1ull); }
                 add = beta * mk3(fr.background[0], fr.background[1], fr.background[2]);  // lib.rs:76
             } else {
                 RtSurface sf;
                 rt_surface(sc, o, d, time, hit, false, sf);
                 RT_TICK(2);
-                v3 atten, dir, emitted;
+                rt_f4 a0 = ld4(sc.materials + 2 * (size_t)sf.mat), a1 = ld4(sc.materials + 2 * (size_t)sf.mat + 1);
+                postponed = may_postpone && f2i(a1.w) != 0;
+                if (!postponed) {
+                    v3 atten, dir, emitted;
 #ifdef RT_SCATTER_TWICE   /* timing experiment */
-                {
-                    RtSurface sf2; v3 at2, dir2, em2;
-                    rt_surface(sc, o, d, time, hit, false, sf2);
-                    bool s2 = rt_scatter(sc, sf2, d, rt_u24(rnd[0]), rt_u24(rnd[1]), at2, dir2, em2);
-                    asm volatile("" : "+v"(o.x), "+v"(d.x), "+v"(at2.x), "+v"(dir2.x), "+v"(em2.x));
-                    if (s2 && at2.x < -1.0f) beta.x = dir2.x + em2.x;   // never true
-                }
-#endif
-                bool scattered = rt_scatter(sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), atten, dir, emitted);
-                RT_TICK(3);
-                if (STATS) {
-                    rt_f4 a0 = ld4(sc.materials + 2 * (size_t)sf.mat);
-                    int mtype = f2i(a0.x), mtex = f2i(a0.y);
-                    atomicAdd(work + 8 + mtype, 1ull);                                     // shades per material kind
-                    if (mtex >= 0 && mtype != RT_MAT_METAL && mtype != RT_MAT_DIELECTRIC) { // texture kind behind the material
-                        int tt = f2i(ld4(sc.textures + 2 * (size_t)mtex).x);
-                        if (tt == RT_TEX_NOISE) atomicAdd(work + 13, 1ull); else if (tt == RT_TEX_CHECKER) atomicAdd(work + 14, 1ull);
+                    {
+                        RtSurface sf2; v3 at2, dir2, em2;
+                        rt_surface(sc, o, d, time, hit, false, sf2);
+                        bool s2 = rt_scatter(sc, sf2, d, rt_u24(rnd[0]), rt_u24(rnd[1]), at2, dir2, em2);
+                        asm volatile("" : "+v"(o.x), "+v"(d.x), "+v"(at2.x), "+v"(dir2.x), "+v"(em2.x));
+                        if (s2 && at2.x < -1.0f) beta.x = dir2.x + em2.x;   // never true
                     }
-                }
-                add = beta * emitted;                                                      // lib.rs:64,66
-                if (scattered && bounce < fr.max_depth) {                                 // lib.rs:58-60
-                    beta = beta * atten;
-                    alive = true;
-                    na.x = sf.p.x; na.y = sf.p.y; na.z = sf.p.z; na.w = time;
-                    nb.x = dir.x; nb.y = dir.y; nb.z = dir.z;
-                    nb.w = i2f(RT_HIT_KIND(hit.code) == RT_KIND_MEDIUM ? (int)RT_HIT_NONE : (int)hit.code);
-                    nc.x = beta.x; nc.y = beta.y; nc.z = beta.z; nc.w = c.w;
+#endif
+                    bool scattered = rt_scatter(sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), atten, dir, emitted);
+                    RT_TICK(3);
+                    if (STATS) {
+                        atomicAdd(work + 5, (unsigned long long)sc.n_media);
+                        int mtype = f2i(a0.x), mtex = f2i(a0.y);
+                        atomicAdd(work + 8 + mtype, 1ull);                                     // shades per material kind
+                        if (mtex >= 0 && mtype != RT_MAT_METAL && mtype != RT_MAT_DIELECTRIC) { // texture kind behind the material
+                            int tt = f2i(ld4(sc.textures + 2 * (size_t)mtex).x);
+                            if (tt == RT_TEX_NOISE) atomicAdd(work + 13, 1ull); else if (tt == RT_TEX_CHECKER) atomicAdd(work + 14, 1ull);
+                        }
+                    }
+                    add = beta * emitted;                                                      // lib.rs:64,66
+                    if (scattered && bounce < fr.max_depth) {                                 // lib.rs:58-60
+                        beta = beta * atten;
+                        alive = true;
+                        na.x = sf.p.x; na.y = sf.p.y; na.z = sf.p.z; na.w = time;
+                        nb.x = dir.x; nb.y = dir.y; nb.z = dir.z;
+                        nb.w = i2f(RT_HIT_KIND(hit.code) == RT_KIND_MEDIUM ? (int)RT_HIT_NONE : (int)hit.code);
+                        nc.x = beta.x; nc.y = beta.y; nc.z = beta.z; nc.w = c.w;
+                    }
                 }
             }
             if (add.x != 0.0f || add.y != 0.0f || add.z != 0.0f) {
@@ -379,6 +382,37 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev f
             }
         }
         RT_TICK(5);
+        return postponed;
+    };
+
+    // Hits on costly textures (Perlin turbulence: ~1300 instructions) are rare per wave but present in every other wave;
+    // evaluated in place they would run with one or two live lanes.  Each wave instead collects their queue indices in
+    // LDS and shades them together, a wave's worth at a time and whatever is left at the end.
+    __shared__ uint32_t s_later[(RT_BLOCK / 64) * 128];
+    uint32_t* later = s_later + (threadIdx.x / 64) * 128;
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool may_postpone = sc.n_perlin > 0;
+    uint32_t n_later = 0;                                              // wave-uniform
+    for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
+        uint32_t i = base + threadIdx.x;
+        bool post = shade(i, i < n, may_postpone);
+        unsigned long long pm = __ballot(post);
+        if (pm) {
+            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+            if (post) later[n_later + rank] = i;
+            n_later += (uint32_t)__popcll(pm);
+            if (n_later >= 64u) {                                      // n_later < 128 always: at most 64 are added to < 64
+                n_later -= 64u;
+                __builtin_amdgcn_wave_barrier();
+                uint32_t j = later[n_later + lane];
+                shade(j, true, false);
+            }
+        }
+    }
+    if (n_later > 0) {
+        __builtin_amdgcn_wave_barrier();
+        uint32_t j = lane < n_later ? later[lane] : 0u;
+        shade(j, lane < n_later, false);
     }
 #ifdef RT_SHADE_CLOCK
     if ((threadIdx.x & 63) == 0) for (int k = 0; k < 8; ++k) if (clk[k]) atomicAdd(work + 20 + k, clk[k]);
@@ -738,7 +772,11 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     local.paths = (uint64_t)n_pixels * (uint64_t)p->spp;
     std::vector<uint32_t> h_counts((size_t)(p->max_depth + 2) * RT_SHARDS * RT_COUNT_STRIDE);
     const size_t counts_bytes = h_counts.size() * sizeof(uint32_t);
-    const int grid_cap = std::max(1, s->n_cu) * 32;
+    // k_shade / k_raygen blocks per CU in the grid (grid-stride loops).  With costly textures in the scene each wave should
+    // see many rays, so that the hits it postpones add up to full waves: then the grid is just what is resident.
+    int shade_bpc = s->view.n_perlin > 0 ? 4 : 32;
+    if (const char* e = std::getenv("RT_SHADE_BLOCKS_PER_CU")) shade_bpc = std::max(1, std::min(64, std::atoi(e)));
+    const int grid_cap = std::max(1, s->n_cu) * shade_bpc;
     const uint32_t cap = (uint32_t)s->ws_cap;
     float* sq = (p->flags & RT_FLAG_SUMSQ) ? d_accum_sq : nullptr;
     const bool instrumented = (p->flags & RT_FLAG_COUNTERS) != 0;

@@ -66,7 +66,8 @@ enum { RT_OP_TRANSLATE = 0, RT_OP_ROTATE_Y = 1 };
 
 // ---- material (materials.rs), 2 x f4:
 //   a0 = int/float (type, texture index or -1, fuzz, ir)     a1 = (rgb, 0): Metal albedo, or the colour of a
-//   SolidColor texture baked in (texture index -1) so that the common case needs no texture fetch
+//   SolidColor texture baked in (texture index -1) so that the common case needs no texture fetch; a1.w = int 1 when the
+//   texture tree holds a Noise (costly to evaluate)
 enum { RT_MAT_LAMBERTIAN = 0, RT_MAT_METAL = 1, RT_MAT_DIELECTRIC = 2, RT_MAT_LIGHT = 3, RT_MAT_ISOTROPIC = 4 };
 #define RT_MATERIAL_F4 2
 
