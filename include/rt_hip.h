@@ -89,7 +89,8 @@ typedef struct RtConfig {                       /* Config, src/main.rs:453-467 *
  * HittableList that main.rs:531 would wrap in BvhNode::new. */
 int rt_config_load(const char* path, RtConfig* out);
 int rt_config_build_scene(const char* path, uint64_t scene_seed, RtBuilder* b, RtObj* world);
-/* One of Random | TwoSpheres | TwoPerlinSpheres | SimpleLight | Cornell | CornellSmoke | FinalScene */
+/* One of Random | TwoSpheres | TwoPerlinSpheres | SimpleLight | Cornell | CornellSmoke | FinalScene (src/main.rs:483-494),
+ * or "Synthetic:<n>" (not in the reference): n random spheres over a 2000 x 2000 field, the deep-BVH traversal stress scene. */
 int rt_canned_scene(RtBuilder* b, const char* scene_type, uint64_t scene_seed, RtObj* world);
 
 /* ------------------------------------------------------------------ flattened scene */

@@ -646,6 +646,28 @@ static int random_scene(Scene& s, SceneRng& rng) {  // main.rs:13-79
     w.push_back(s.sphere(V3(4, 1, 0), 1.0, s.metal(V3(0.7, 0.6, 0.5), 0.0)));
     return s.list(w.data(), (int)w.size());
 }
+// "Synthetic:<n>" -- the library's traversal stress scene (no counterpart in the reference): same draws, same order.
+static int synthetic_scene(Scene& s, int n, SceneRng& rng) {
+    std::vector<int> w;
+    w.push_back(s.sphere(V3(0, -100000, 0), 100000, lambert_color(s, V3(0.5, 0.5, 0.5))));
+    for (int i = 0; i < n; ++i) {
+        double choose = rng.gen();
+        double cx = rng.range(-1000.0, 1000.0), cy = rng.range(0.0, 200.0), cz = rng.range(-1000.0, 1000.0);
+        double rad = rng.range(0.2, 2.0);
+        int m;
+        if (choose < 0.8) {
+            double g[6];
+            for (int q = 0; q < 6; ++q) g[q] = rng.gen();
+            m = lambert_color(s, cmul(V3(g[0], g[1], g[2]), V3(g[3], g[4], g[5])));
+        } else if (choose < 0.95) {
+            double r = rng.range(0.5, 1.0), g = rng.range(0.5, 1.0), bl = rng.range(0.5, 1.0);
+            double fuzz = rng.range(0.0, 0.5);
+            m = s.metal(V3(r, g, bl), fuzz);
+        } else m = s.dielectric(1.5);
+        w.push_back(s.sphere(V3(cx, cy, cz), rad, m));
+    }
+    return s.list(w.data(), (int)w.size());
+}
 static int two_spheres(Scene& s) {  // main.rs:81-100
     int checker = s.checker(s.solid(V3(0.2, 0.3, 0.1)), s.solid(V3(0.9, 0.9, 0.9)));
     int w[2] = {s.sphere(V3(0, -10, 0), 10, s.lambertian(checker)), s.sphere(V3(0, 10, 0), 10, s.lambertian(checker))};
@@ -864,6 +886,7 @@ int orc_canned(OrcScene* s, const char* type, uint64_t scene_seed) {
     if (t == "Cornell") return cornell_box(s->s);
     if (t == "CornellSmoke") return cornell_smoke(s->s);
     if (t == "FinalScene") return final_scene(s->s, rng);
+    if (t.compare(0, 10, "Synthetic:") == 0) return synthetic_scene(s->s, std::atoi(t.c_str() + 10), rng);
     return -1;
 }
 // main.rs:531 -- world = BvhNode::new(list, 0, 1).  use_bvh = 0 keeps the plain list (brute force).

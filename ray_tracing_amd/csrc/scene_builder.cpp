@@ -2,6 +2,7 @@
 // main.rs:13-451 and the thin-lens camera frame of cameras.rs:38-79.
 #include "scene_builder.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace rt {
 
@@ -168,6 +169,32 @@ HittableObj random_scene(Builder& b, SceneRng& rng) {  // main.rs:13-79
     return b.list(w);
 }
 
+// Stress scene for deep-BVH traversal (not in the reference): n small spheres over a 2000 x 2000 field above a huge
+// ground sphere, materials drawn 80 / 15 / 5 % Lambertian / metal / glass with the parameter rules of main.rs:43-66.
+HittableObj synthetic_scene(Builder& b, int n, SceneRng& rng) {
+    std::vector<HittableObj> w;
+    w.reserve((size_t)n + 1);
+    w.push_back(b.sphere(vec3(0, -100000, 0), 100000, b.lambertian(vec3(0.5, 0.5, 0.5))));
+    for (int i = 0; i < n; ++i) {
+        double choose = rng.gen();
+        double cx = rng.range(-1000.0, 1000.0), cy = rng.range(0.0, 200.0), cz = rng.range(-1000.0, 1000.0);
+        double r = rng.range(0.2, 2.0);
+        Material m;
+        if (choose < 0.8) {
+            double a1[3], a2[3];
+            for (double& v : a1) v = rng.gen();
+            for (double& v : a2) v = rng.gen();
+            m = b.lambertian(vec3(a1[0] * a2[0], a1[1] * a2[1], a1[2] * a2[2]));
+        } else if (choose < 0.95) {
+            double cr = rng.range(0.5, 1.0), cg = rng.range(0.5, 1.0), cb = rng.range(0.5, 1.0);
+            double fuzz = rng.range(0.0, 0.5);
+            m = b.metal(vec3(cr, cg, cb), fuzz);
+        } else m = b.dielectric(1.5);
+        w.push_back(b.sphere(vec3(cx, cy, cz), r, m));
+    }
+    return b.list(w);
+}
+
 HittableObj two_spheres(Builder& b) {  // main.rs:81-100
     Texture ck = b.checker_from_solid_colors(vec3(0.2, 0.3, 0.1), vec3(0.9, 0.9, 0.9));
     std::vector<HittableObj> w;
@@ -264,6 +291,11 @@ HittableObj canned_scene(Builder& b, const std::string& type, uint64_t seed) {  
     if (type == "Cornell") return cornell_box(b);
     if (type == "CornellSmoke") return cornell_smoke(b);
     if (type == "FinalScene") return final_scene(b, rng);
+    if (type.compare(0, 10, "Synthetic:") == 0) {
+        long n = std::strtol(type.c_str() + 10, nullptr, 10);
+        if (n < 1 || n > 50000000) { b.error = "Synthetic:<n> needs 1 <= n <= 50000000"; return -1; }
+        return synthetic_scene(b, (int)n, rng);
+    }
     b.error = "unknown scene type '" + type + "'";
     return -1;
 }

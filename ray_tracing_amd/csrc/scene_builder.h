@@ -102,6 +102,7 @@ HittableObj simple_light(Builder& b, SceneRng& rng);
 HittableObj cornell_box(Builder& b);
 HittableObj cornell_smoke(Builder& b);
 HittableObj final_scene(Builder& b, SceneRng& rng);
+HittableObj synthetic_scene(Builder& b, int n, SceneRng& rng);   // "Synthetic:<n>": n random spheres (traversal stress, not in the reference)
 HittableObj canned_scene(Builder& b, const std::string& type, uint64_t scene_seed);  // -1: unknown type
 
 // ---- Config (main.rs:453-494, cameras.rs:10-18, objects.rs:104-107,248-253, materials.rs:34-40)

@@ -89,3 +89,51 @@ def test_deep_bvh_synthetic_spheres(gpu_required):
     accum, _, st = scene.render(cam, rt.render_params(W, H, 4, 50, RENDER_SEED, background=(0.7, 0.8, 1.0)))
     assert np.isfinite(accum).all() and st.rays > W * H * 4
     scene.close()
+
+
+def _synthetic_pair(n):
+    b, ob = rt.Builder(), OracleBuilder()
+    w = b.canned_scene("Synthetic:%d" % n, SCENE_SEED)
+    ob.set_world(ob.canned_scene("Synthetic:%d" % n, SCENE_SEED))
+    return b, w, ob
+
+
+def test_synthetic_sphere_field_matches_oracle(gpu_required):
+    """The deep-BVH stress config at 60k spheres: built by the library's and by the oracle's own builder from the same seed."""
+    b, w, ob = _synthetic_pair(60000)
+    scene = rt.Scene(b, w, 0)
+    assert scene.info().n_spheres == 60001
+    cam = rt.make_camera((0, 260, 1500), (0, 60, 0), (0, 1, 0), 40.0, 16 / 9, 0.1, 10.0)
+    W, H = 480, 270
+    g = scene.trace_primary(cam, rt.render_params(W, H, 1, 50, RENDER_SEED), 0)
+    o = oracle_trace_primary(ob, OracleCamera(cam), W, H, 0, RENDER_SEED)
+    agree, rel = primary_agreement(g, o)
+    assert agree >= 0.9999 and rel <= 1e-4, (agree, rel)
+    scene.close()
+
+
+@pytest.mark.parametrize("env", [{"RT_TRACE_WIDE_STACK": "1"}, {"RT_TRACE_BLOCK": "256"}])
+@pytest.mark.parametrize("name", ["cornell.yml", "final_scene.yml"])
+def test_trace_kernel_variants_agree(gpu_required, name, env):
+    """k_trace picks its block shape, stack form and what lives in LDS per scene; every choice must give the very same image."""
+    cfg, cam = config_camera(name)
+    p = rt.render_params(200, 200, 4, cfg.max_depth, RENDER_SEED)
+
+    def render():
+        b = rt.Builder()
+        scene = rt.Scene(b, b.scene_from_config(os.path.join(CONFIGS, name), SCENE_SEED), 0)
+        img, _, st = scene.render(cam, p)
+        scene.close()
+        return img, st.rays
+    want, rays = render()
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        got, rays2 = render()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert rays2 == rays and np.array_equal(got, want)
