@@ -760,9 +760,10 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     RtCameraDev cd; make_cam(cam, cd);
     RtFrameDev fr; make_frame(p, fr);
     const size_t n_pixels = (size_t)fr.n_pixels;
-    // Default pass: up to 2^26 paths in flight (7.5 GB of queues).  The late bounces of a pass are latency-bound
-    // (a few long rays per launch), so their fixed cost is amortised over as many paths as fit comfortably in HBM.
-    size_t target = p->paths_per_pass > 0 ? (size_t)p->paths_per_pass : ((size_t)1 << 26);
+    // Default pass: up to 2^28 paths in flight (34 GB of queues, hit and contribution slots on a 288 GB part).  Late
+    // bounces hold few rays per launch and run below the bulk rate; the more paths share a pass, the less that costs
+    // (final_scene.yml: +10 % from 2^26 to 2^28).
+    size_t target = p->paths_per_pass > 0 ? (size_t)p->paths_per_pass : ((size_t)1 << 28);
     int chunk_max = (int)std::max<size_t>(1, target / n_pixels);
     if ((size_t)chunk_max * n_pixels > 0xFFFFFFF0ull) chunk_max = (int)(0xFFFFFFF0ull / n_pixels);
     chunk_max = std::min(chunk_max, std::max(1, p->spp));
