@@ -1,8 +1,10 @@
 //! Replacement of the pixel / sample loop of main() (src/main.rs:567-599): flatten, upload, render, tonemap.
 use crate::flatten::Flatten;
 use crate::hip::{self, check, RtCamera, RtRenderParams};
-use crate::{cameras::CameraConfig, utils::get_pixel, Color, HittableList};
+use crate::{cameras::CameraConfig, utils::{get_pixel, SerdeVector}, Color, HittableList, Vec3};
 use image::RgbImage;
+
+fn arr(v: &SerdeVector) -> [f64; 3] { let v: Vec3 = v.clone().into(); [v[0], v[1], v[2]] }   // utils.rs:93-102
 
 pub struct GpuOptions { pub device: i32, pub seed: u64, pub background: [f32; 3] }
 
@@ -17,7 +19,7 @@ pub fn render_on_gpu(world: &HittableList, cam: &CameraConfig, width: u32, heigh
         hip::rtb_destroy(b);                                        // the scene keeps its own copy
         rc?;
         let camera = RtCamera {
-            look_from: cam.look_from.into(), look_at: cam.look_at.into(), v_up: cam.v_up.into(),
+            look_from: arr(&cam.look_from), look_at: arr(&cam.look_at), v_up: arr(&cam.v_up),
             vertical_fov_deg: cam.vertical_fov_deg, aspect_ratio: cam.aspect_ratio, aperture: cam.aperture,
             focus_dist: cam.focus_distance, shutter_open: 0.0, shutter_close: 1.0,          // main.rs:544-545
         };
