@@ -173,6 +173,15 @@ int rt_scatter_rays(RtScene* s, const float* rays, int32_t n, uint32_t pixel0, u
 int rt_tonemap_u8(const float* accum_rgb, int32_t n_pixels, int32_t spp, uint8_t* rgb);
 /* Writes a binary PPM (P6) of the tonemapped image. */
 int rt_write_ppm(const char* path, const uint8_t* rgb, int32_t width, int32_t height);
+/* out_image.save(output) of src/main.rs:600: the format follows the file extension as in the `image` crate.  Supported here:
+ * .png (8-bit RGB, stored deflate) and .ppm; anything else is RT_ERR_UNSUPPORTED. */
+int rt_write_image(const char* path, const uint8_t* rgb, int32_t width, int32_t height);
+/* Checkpoints of the accumulation buffer, so that a long render (configs/final_scene.yml asks for 100 000 spp) can stop and
+ * resume: the next call renders with sample_offset = spp_done.  The reference has nothing of the kind (src/main.rs:601 saves
+ * once, at the end).  Load fails unless the file holds an image of the given size; *seed (may be NULL) receives the render seed
+ * the checkpoint was made with. */
+int rt_accum_save(const char* path, const float* accum_rgb, int32_t width, int32_t height, int64_t spp_done, uint64_t seed);
+int rt_accum_load(const char* path, float* accum_rgb, int32_t width, int32_t height, int64_t* spp_done, uint64_t* seed);
 
 #ifdef __cplusplus
 }

@@ -102,6 +102,9 @@ API = {
     "rt_scatter_rays": (C.c_int, [_P, _P, C.c_int32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint64, _P]),
     "rt_tonemap_u8": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "rt_write_ppm": (C.c_int, [C.c_char_p, _P, C.c_int32, C.c_int32]),
+    "rt_write_image": (C.c_int, [C.c_char_p, _P, C.c_int32, C.c_int32]),
+    "rt_accum_save": (C.c_int, [C.c_char_p, _P, C.c_int32, C.c_int32, C.c_int64, C.c_uint64]),
+    "rt_accum_load": (C.c_int, [C.c_char_p, _P, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_uint64)]),
 }
 
 
@@ -337,3 +340,22 @@ def tonemap_u8(accum, spp):
 def write_ppm(path, rgb):
     rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
     _check(lib().rt_write_ppm(path.encode(), rgb.ctypes.data, rgb.shape[1], rgb.shape[0]))
+
+
+def write_image(path, rgb):
+    """Saves an 8-bit RGB image; the format follows the extension (.png or .ppm), as `image::save` does in main.rs:600."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    _check(lib().rt_write_image(path.encode(), rgb.ctypes.data, rgb.shape[1], rgb.shape[0]))
+
+
+def accum_save(path, accum, spp_done, seed):
+    accum = np.ascontiguousarray(accum, dtype=np.float32)
+    _check(lib().rt_accum_save(path.encode(), accum.ctypes.data, accum.shape[1], accum.shape[0], spp_done, seed))
+
+
+def accum_load(path, height, width):
+    """Returns (accum, spp_done, seed) of a checkpoint written by accum_save."""
+    accum = np.zeros((height, width, 3), dtype=np.float32)
+    spp, seed = C.c_int64(0), C.c_uint64(0)
+    _check(lib().rt_accum_load(path.encode(), accum.ctypes.data, width, height, C.byref(spp), C.byref(seed)))
+    return accum, spp.value, seed.value

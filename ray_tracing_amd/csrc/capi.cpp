@@ -4,6 +4,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cctype>
+#include <vector>
 #include "capi_internal.h"
 
 thread_local std::string g_rt_error;
@@ -140,6 +142,91 @@ int rt_write_ppm(const char* path, const uint8_t* rgb, int32_t w, int32_t h) {
     size_t n = (size_t)w * h * 3, wr = std::fwrite(rgb, 1, n, f);
     std::fclose(f);
     return wr == n ? RT_OK : rt_set_error(RT_ERR_INVALID, "short write");
+}
+
+// ---- PNG with stored (uncompressed) deflate blocks: a valid file every decoder reads, no compression library needed.
+static uint32_t crc32_update(uint32_t crc, const uint8_t* p, size_t n) {
+    static uint32_t table[256];
+    static bool ready = false;
+    if (!ready) {
+        for (uint32_t i = 0; i < 256; ++i) { uint32_t c = i; for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1; table[i] = c; }
+        ready = true;
+    }
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+    return crc;
+}
+static void be32(std::vector<uint8_t>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
+static void png_chunk(std::vector<uint8_t>& out, const char type[4], const std::vector<uint8_t>& data) {
+    be32(out, (uint32_t)data.size());
+    size_t at = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), data.begin(), data.end());
+    be32(out, crc32_update(0xFFFFFFFFu, out.data() + at, out.size() - at) ^ 0xFFFFFFFFu);
+}
+static int write_png(const char* path, const uint8_t* rgb, int32_t w, int32_t h) {
+    std::vector<uint8_t> raw;                                  // scanlines, each with filter byte 0
+    raw.reserve((size_t)h * (3 * (size_t)w + 1));
+    for (int y = 0; y < h; ++y) { raw.push_back(0); raw.insert(raw.end(), rgb + (size_t)y * w * 3, rgb + (size_t)(y + 1) * w * 3); }
+    std::vector<uint8_t> z; z.push_back(0x78); z.push_back(0x01);   // zlib header, then stored blocks of <= 65535 bytes
+    uint32_t a = 1, b2 = 0;                                     // Adler-32 of raw
+    for (size_t i = 0; i < raw.size(); ++i) { a = (a + raw[i]) % 65521u; b2 = (b2 + a) % 65521u; }
+    for (size_t off = 0; off < raw.size() || off == 0; off += 65535) {
+        size_t n = std::min<size_t>(65535, raw.size() - off);
+        z.push_back(off + n >= raw.size() ? 1 : 0);
+        z.push_back(n & 0xFF); z.push_back(n >> 8); z.push_back(~n & 0xFF); z.push_back((~n >> 8) & 0xFF);
+        z.insert(z.end(), raw.begin() + off, raw.begin() + off + n);
+        if (raw.empty()) break;
+    }
+    be32(z, (b2 << 16) | a);
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A}, ihdr;
+    be32(ihdr, (uint32_t)w); be32(ihdr, (uint32_t)h);
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);   // 8-bit RGB, no interlace
+    png_chunk(out, "IHDR", ihdr); png_chunk(out, "IDAT", z); png_chunk(out, "IEND", std::vector<uint8_t>());
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return rt_set_error(RT_ERR_INVALID, std::string("cannot open ") + path);
+    size_t wr = std::fwrite(out.data(), 1, out.size(), f);
+    std::fclose(f);
+    return wr == out.size() ? RT_OK : rt_set_error(RT_ERR_INVALID, "short write");
+}
+
+int rt_write_image(const char* path, const uint8_t* rgb, int32_t w, int32_t h) {
+    if (!path || !rgb || w <= 0 || h <= 0) return rt_set_error(RT_ERR_INVALID, "bad argument");
+    std::string p(path);
+    size_t dot = p.find_last_of('.');
+    std::string ext = dot == std::string::npos ? "" : p.substr(dot + 1);
+    for (char& c : ext) c = (char)std::tolower((unsigned char)c);
+    if (ext == "png") return write_png(path, rgb, w, h);
+    if (ext == "ppm" || ext == "pnm") return rt_write_ppm(path, rgb, w, h);
+    return rt_set_error(RT_ERR_UNSUPPORTED, "image format '" + ext + "' is not supported (png, ppm)");
+}
+
+// ---- accumulator checkpoints: header {magic, width, height, spp_done, seed} then width * height * 3 floats
+static const uint64_t kAccumMagic = 0x314D554343415452ull;  // "RTACCUM1"
+int rt_accum_save(const char* path, const float* accum_rgb, int32_t w, int32_t h, int64_t spp_done, uint64_t seed) {
+    if (!path || !accum_rgb || w <= 0 || h <= 0 || spp_done < 0) return rt_set_error(RT_ERR_INVALID, "bad argument");
+    std::string tmp = std::string(path) + ".tmp";              // written aside and renamed: a crash never leaves half a file
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return rt_set_error(RT_ERR_INVALID, "cannot open " + tmp);
+    uint64_t hdr[5] = {kAccumMagic, (uint64_t)w, (uint64_t)h, (uint64_t)spp_done, seed};
+    size_t n = (size_t)w * h * 3;
+    bool ok = std::fwrite(hdr, sizeof(hdr), 1, f) == 1 && std::fwrite(accum_rgb, sizeof(float), n, f) == n;
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok || std::rename(tmp.c_str(), path) != 0) return rt_set_error(RT_ERR_INVALID, std::string("cannot write ") + path);
+    return RT_OK;
+}
+int rt_accum_load(const char* path, float* accum_rgb, int32_t w, int32_t h, int64_t* spp_done, uint64_t* seed) {
+    if (!path || !accum_rgb || !spp_done || w <= 0 || h <= 0) return rt_set_error(RT_ERR_INVALID, "bad argument");
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return rt_set_error(RT_ERR_INVALID, std::string("cannot open ") + path);
+    uint64_t hdr[5];
+    size_t n = (size_t)w * h * 3;
+    bool ok = std::fread(hdr, sizeof(hdr), 1, f) == 1 && hdr[0] == kAccumMagic && hdr[1] == (uint64_t)w && hdr[2] == (uint64_t)h &&
+              std::fread(accum_rgb, sizeof(float), n, f) == n;
+    std::fclose(f);
+    if (!ok) return rt_set_error(RT_ERR_INVALID, std::string(path) + " is not an accumulator checkpoint of this image size");
+    *spp_done = (int64_t)hdr[3];
+    if (seed) *seed = hdr[4];
+    return RT_OK;
 }
 
 }  // extern "C"

@@ -1,9 +1,14 @@
 // rt_cli.cpp -- command-line driver with the flags of the reference binary (main.rs:496-504):
-//   rt_cli -c <config.yml> [-o <image.ppm>]      plus  --spp N  --seed N  --scene-seed N  --device N  --background r,g,b
+//   rt_cli -c <config.yml> [-o <image.png|.ppm>]  plus  --spp N  --seed N  --scene-seed N  --device N  --background r,g,b
+//                                                       --checkpoint <file>  --pass-spp N
 // It does what main() does (main.rs:506-601) with the render loop replaced by rt_render: read the
 // config, build the scene, render samples_per_pixel samples, tonemap (utils.rs:49-63), save.
-// Output is a binary PPM of the same 8-bit values the reference hands to its image encoder
-// (its default is a lossy JPEG, main.rs:502).
+// The output format follows the extension (main.rs:600); the 8-bit values are the ones the reference
+// hands to its image encoder (its default is a lossy JPEG, main.rs:502).
+// With --checkpoint the samples are rendered --pass-spp at a time (default 1024); the accumulation buffer
+// is saved after every pass and an existing checkpoint is continued, so configs/final_scene.yml's
+// 100 000 spp can be stopped and resumed.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -14,7 +19,8 @@
 static int die(const char* what) { std::fprintf(stderr, "rt_cli: %s: %s\n", what, rt_last_error()); return 1; }
 
 int main(int argc, char** argv) {
-    std::string config, output = "./image.ppm";
+    std::string config, output = "./image.ppm", checkpoint;
+    long long pass_spp = 1024;
     long long spp_override = -1; unsigned long long seed = 0x5EED0002ull, scene_seed = 0x5EED0001ull; int device = 0;
     float bg[3] = {0, 0, 0};
     for (int i = 1; i < argc; ++i) {
@@ -26,8 +32,10 @@ int main(int argc, char** argv) {
         else if (a == "--seed") seed = std::strtoull(next("--seed"), nullptr, 0);
         else if (a == "--scene-seed") scene_seed = std::strtoull(next("--scene-seed"), nullptr, 0);
         else if (a == "--device") device = std::atoi(next("--device"));
+        else if (a == "--checkpoint") checkpoint = next("--checkpoint");
+        else if (a == "--pass-spp") pass_spp = std::max(1LL, std::atoll(next("--pass-spp")));
         else if (a == "--background") { if (std::sscanf(next("--background"), "%f,%f,%f", &bg[0], &bg[1], &bg[2]) != 3) { std::fprintf(stderr, "rt_cli: --background r,g,b\n"); return 2; } }
-        else { std::fprintf(stderr, "usage: rt_cli -c <config.yml> [-o <image.ppm>] [--spp N] [--seed N] [--scene-seed N] [--device N] [--background r,g,b]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: rt_cli -c <config.yml> [-o <image.ppm>] [--spp N] [--seed N] [--scene-seed N] [--device N] [--background r,g,b] [--checkpoint <file>] [--pass-spp N]\n"); return 2; }
     }
     if (config.empty()) { std::fprintf(stderr, "rt_cli: the following required arguments were not provided: --config <CONFIG>\n"); return 2; }
 
@@ -49,13 +57,31 @@ int main(int argc, char** argv) {
     p.max_depth = cfg.max_depth; p.seed = seed; std::memcpy(p.background, bg, sizeof(bg));
 
     std::vector<float> accum((size_t)p.width * p.height * 3, 0.0f);
-    RtStats st;
-    if (rt_render(scene, &cam, &p, accum.data(), nullptr, &st)) return die("rt_render");
+    const int total_spp = p.spp;
+    long long done = 0;
+    if (!checkpoint.empty()) {
+        int64_t have = 0; uint64_t ck_seed = 0;
+        if (rt_accum_load(checkpoint.c_str(), accum.data(), p.width, p.height, &have, &ck_seed) == RT_OK) {
+            if (ck_seed != seed) { std::fprintf(stderr, "rt_cli: %s was rendered with seed %llu, not %llu\n", checkpoint.c_str(), (unsigned long long)ck_seed, (unsigned long long)seed); return 1; }
+            done = std::min<long long>(have, total_spp);
+            std::fprintf(stderr, "rt_cli: resuming %s at %lld of %d spp\n", checkpoint.c_str(), done, total_spp);
+        } else std::fill(accum.begin(), accum.end(), 0.0f);     // no usable checkpoint: start from scratch
+    }
+    RtStats st, total; std::memset(&total, 0, sizeof(total));
+    while (done < total_spp) {
+        p.spp = checkpoint.empty() ? total_spp : (int)std::min<long long>(pass_spp, total_spp - done);
+        p.sample_offset = (int)done;
+        if (rt_render(scene, &cam, &p, accum.data(), nullptr, &st)) return die("rt_render");
+        total.rays += st.rays; total.seconds += st.seconds;
+        done += p.spp;
+        if (!checkpoint.empty() && rt_accum_save(checkpoint.c_str(), accum.data(), p.width, p.height, done, seed)) return die("checkpoint");
+    }
+    st = total; p.spp = total_spp;
     std::vector<uint8_t> rgb(accum.size());
     if (rt_tonemap_u8(accum.data(), p.width * p.height, p.spp, rgb.data())) return die("tonemap");
-    if (rt_write_ppm(output.c_str(), rgb.data(), p.width, p.height)) return die("write");
+    if (rt_write_image(output.c_str(), rgb.data(), p.width, p.height)) return die("write");
     std::fprintf(stderr, "%s: %dx%d, %d spp, depth %d: %.3f s, %llu ray segments, %.1f Mrays/s -> %s\n", cfg.scene_type, p.width, p.height, p.spp,
-                 p.max_depth, st.seconds, (unsigned long long)st.rays, st.rays / st.seconds / 1e6, output.c_str());
+                 p.max_depth, st.seconds, (unsigned long long)st.rays, st.seconds > 0 ? st.rays / st.seconds / 1e6 : 0.0, output.c_str());
     rt_scene_destroy(scene);
     return 0;
 }

@@ -176,3 +176,39 @@ def test_tonemap_matches_utils_rs():  # utils.rs:49-63
     acc = np.array([[0.25 * spp, 1.0 * spp, 0.0], [4.0 * spp, -1.0, 0.5 * spp]], dtype=np.float32)
     rgb = rt.tonemap_u8(acc, spp)
     assert rgb.tolist() == [[128, 255, 0], [255, 0, int(256 * np.sqrt(0.5))]]
+
+
+def test_png_and_ppm_writers_and_checkpoints(tmp_path):
+    """rt_write_image follows the extension (main.rs:600); the PNG is decoded here with zlib.  Accumulator checkpoints round-trip."""
+    import struct
+    import zlib
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    png = str(tmp_path / "a.png")
+    rt.write_image(png, rgb)
+    data = open(png, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, ihdr = 8, b"", None
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + body)
+        if typ == b"IHDR": ihdr = struct.unpack(">IIBBBBB", body)
+        if typ == b"IDAT": idat += body
+        pos += 12 + n
+    assert ihdr == (53, 37, 8, 2, 0, 0, 0)
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(37, 1 + 53 * 3)
+    assert np.all(raw[:, 0] == 0) and np.array_equal(raw[:, 1:].reshape(37, 53, 3), rgb)
+    ppm = str(tmp_path / "a.ppm")
+    rt.write_image(ppm, rgb)
+    assert open(ppm, "rb").read() == b"P6\n53 37\n255\n" + rgb.tobytes()
+    with pytest.raises(rt.RtError) as e:
+        rt.write_image(str(tmp_path / "a.jpg"), rgb)
+    assert e.value.code == -6
+    acc = rng.random((37, 53, 3), dtype=np.float32) * 100
+    ck = str(tmp_path / "acc.bin")
+    rt.accum_save(ck, acc, 1234, 0x5EED0002)
+    got, spp, seed = rt.accum_load(ck, 37, 53)
+    assert np.array_equal(got, acc) and spp == 1234 and seed == 0x5EED0002
+    with pytest.raises(rt.RtError):
+        rt.accum_load(ck, 53, 37)                      # a checkpoint of another image size is refused

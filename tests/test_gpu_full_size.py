@@ -137,3 +137,40 @@ def test_trace_kernel_variants_agree(gpu_required, name, env):
             else:
                 os.environ[k] = v
     assert rays2 == rays and np.array_equal(got, want)
+
+
+def test_cli_checkpoint_and_resume(gpu_required, tmp_path):
+    """rt_cli renders in passes with --checkpoint, continues an existing checkpoint, and writes PNG by extension."""
+    import subprocess
+    import zlib
+    cli = os.path.join(os.path.dirname(rt.LIB_PATH), "rt_cli")
+    cfg = os.path.join(CONFIGS, "cornell.yml")
+    ck, out1, out2 = str(tmp_path / "acc.bin"), str(tmp_path / "a.png"), str(tmp_path / "b.png")
+
+    def run(*args):
+        r = subprocess.run([cli, "-c", cfg] + list(args), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        return r.stderr
+
+    run("-o", out1, "--spp", "8", "--checkpoint", ck, "--pass-spp", "3")           # 3 + 3 + 2 samples, saved after each pass
+    acc, spp, seed = rt.accum_load(ck, 600, 600)
+    assert spp == 8 and seed == 0x5EED0002 and acc.mean() > 0
+    log = run("-o", out2, "--spp", "12", "--checkpoint", ck, "--pass-spp", "4")    # continues at sample 8
+    assert "resuming" in log and "at 8 of 12" in log
+    acc2, spp2, _ = rt.accum_load(ck, 600, 600)
+    assert spp2 == 12 and np.all(acc2 >= acc)                                       # samples only add light
+
+    def decode(path):
+        data = open(path, "rb").read()
+        pos, idat = 8, b""
+        while pos < len(data):
+            n = int.from_bytes(data[pos:pos + 4], "big")
+            if data[pos + 4:pos + 8] == b"IDAT": idat += data[pos + 8:pos + 8 + n]
+            pos += 12 + n
+        return np.frombuffer(zlib.decompress(idat), np.uint8).reshape(600, 1 + 1800)[:, 1:].reshape(600, 600, 3)
+    img = decode(out2)
+    _, cam, scene = load("cornell.yml")
+    whole, _, _ = scene.render(cam, rt.render_params(600, 600, 12, 50, RENDER_SEED))  # the same 12 samples in one pass
+    scene.close()
+    want = rt.tonemap_u8(whole, 12)
+    assert np.abs(img.astype(int) - want.astype(int)).max() <= 1                    # fp32 summation order only

@@ -1,5 +1,3 @@
 set -e
-for v in sw4 sw5 sw6; do for c in final_scene.yml cornell.yml; do
-  echo -n "$v $c: "
-  RT_VARIANT_LIB=ray_tracing_amd/variants/$v.so timeout -k 10 150 python3 tools/profile_driver.py $c 64 3 0 4 2>&1 | tail -2 | head -1
-done; done
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 200 --timeout-method thread 2>&1 | tail -3
+timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
