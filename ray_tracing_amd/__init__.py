@@ -32,7 +32,8 @@ class RtConfig(C.Structure):
                 ("max_depth", C.c_int32), ("look_from", C.c_double * 3), ("look_at", C.c_double * 3),
                 ("v_up", C.c_double * 3), ("vertical_fov_deg", C.c_double), ("aspect_ratio", C.c_double),
                 ("aperture", C.c_double), ("focus_distance", C.c_double), ("scene_type", C.c_char * 32),
-                ("n_list_objects", C.c_int32)]
+                ("n_list_objects", C.c_int32), ("shutter_open", C.c_double), ("shutter_close", C.c_double),
+                ("background", C.c_float * 3)]
 
 
 class RtSceneInfo(C.Structure):
@@ -241,8 +242,10 @@ def load_config(path):
     return cfg
 
 
-def camera_from_config(cfg, shutter_open=0.0, shutter_close=1.0):
-    """Camera::new as main.rs:536-547 calls it (shutter hard-coded to 0..1 there)."""
+def camera_from_config(cfg, shutter_open=None, shutter_close=None):
+    """Camera::new as main.rs:536-547 calls it (the shutter is 0..1 there; a config may set camera.shutter_open / shutter_close)."""
+    shutter_open = cfg.shutter_open if shutter_open is None else shutter_open
+    shutter_close = cfg.shutter_close if shutter_close is None else shutter_close
     cam = RtCamera()
     for i in range(3):
         cam.look_from[i], cam.look_at[i], cam.v_up[i] = cfg.look_from[i], cfg.look_at[i], cfg.v_up[i]

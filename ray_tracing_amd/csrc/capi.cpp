@@ -82,7 +82,9 @@ static void fill_config(const rt::Config& c, RtConfig* o) {
     o->vertical_fov_deg = c.camera.vertical_fov_deg; o->aspect_ratio = c.camera.aspect_ratio; o->aperture = c.camera.aperture;
     o->focus_distance = c.camera.focus_distance;
     std::snprintf(o->scene_type, sizeof(o->scene_type), "%s", c.scene_type.c_str());
-    o->n_list_objects = (int32_t)c.objects.size();
+    o->n_list_objects = c.n_list_objects;
+    o->shutter_open = c.shutter_open; o->shutter_close = c.shutter_close;
+    o->background[0] = (float)c.background.x; o->background[1] = (float)c.background.y; o->background[2] = (float)c.background.z;
 }
 int rt_config_load(const char* path, RtConfig* out) {
     if (!path || !out) return rt_set_error(RT_ERR_INVALID, "null argument");

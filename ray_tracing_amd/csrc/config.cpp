@@ -142,24 +142,126 @@ bool get_vec(const YNode* n, Vec3& out) {  // utils.rs:92-97 SerdeVector {x, y, 
     if (!n || n->kind != YNode::Map) return false;
     return get_f64(n->get("x"), out.x) && get_f64(n->get("y"), out.y) && get_f64(n->get("z"), out.z);
 }
-bool get_spheres(const YNode* list, std::vector<SphereConfig>& out) {  // objects.rs:104-107, 248-253
-    if (!list || list->kind != YNode::Seq) return false;
-    for (auto& item : list->seq) {
-        SphereConfig s = {};
-        const YNode* m = item->get("material");
-        if (!get_vec(item->get("center"), s.center) || !get_f64(item->get("radius"), s.radius) || !m || m->kind != YNode::Map) return false;
-        const YNode* ty = m->get("type");  // materials.rs:34-40, internally tagged
-        if (!ty || ty->kind != YNode::Scalar) return false;
-        if (ty->scalar == "Lambertian") { s.mat_type = RT_MAT_LAMBERTIAN; if (!get_vec(m->get("albedo"), s.albedo)) return false; }
-        else if (ty->scalar == "Metal") { s.mat_type = RT_MAT_METAL; if (!get_vec(m->get("albedo"), s.albedo) || !get_f64(m->get("fuzz"), s.fuzz)) return false; }
-        else if (ty->scalar == "Dielectric") { s.mat_type = RT_MAT_DIELECTRIC; if (!get_f64(m->get("ir"), s.ir)) return false; }
-        else return false;
-        out.push_back(s);
+// ---- "List" scenes beyond the reference's schema.  The reference's List holds spheres with three materials
+// (objects.rs:102-107, materials.rs:34-40; "TODO make this more generic", objects.rs:102).  Here an item may carry a `type`:
+//   Sphere (default) {center, radius, material}        MovingSphere {center0, center1, time0, time1, radius, material}
+//   Rectangle {plane: Xy|Xz|Yz, x0, x1, y0, y1, k, material}        Box {min, max, material}
+//   Translate {offset, object}    RotateY {angle_deg, object}    ConstantMedium {boundary, density, albedo}    List {objects}
+// material: Lambertian {albedo | texture}, Metal {albedo, fuzz}, Dielectric {ir}, DiffuseLight {color | texture}, Isotropic {albedo | texture}
+// texture:  a colour {x, y, z}, or {type: SolidColor, color} | {type: Checker, even, odd} | {type: Noise, scale}
+// A Noise draws its Perlin tables from the scene stream, in document order.
+struct SceneReader {
+    Builder& b; SceneRng& rng; std::string err;
+    SceneReader(Builder& b_, SceneRng& r) : b(b_), rng(r) {}
+    int fail(const std::string& m) { if (err.empty()) err = m; return -1; }
+    static std::string type_of(const YNode* n, const char* dflt) {
+        const YNode* t = n ? n->get("type") : nullptr;
+        return t && t->kind == YNode::Scalar ? t->scalar : std::string(dflt);
     }
-    return true;
-}
+    int texture(const YNode* n) {
+        if (!n || n->kind != YNode::Map) return fail("texture: expected a mapping");
+        Vec3 c;
+        if (!n->get("type")) { if (!get_vec(n, c)) return fail("texture: expected {x, y, z} or a typed texture"); return b.solid_color(c); }
+        std::string t = type_of(n, "");
+        if (t == "SolidColor") { if (!get_vec(n->get("color"), c)) return fail("SolidColor: color"); return b.solid_color(c); }
+        if (t == "Checker") {
+            int e = texture(n->get("even")); if (e < 0) return -1;
+            int o = texture(n->get("odd")); if (o < 0) return -1;
+            return b.checker(e, o);
+        }
+        if (t == "Noise") { double sc; if (!get_f64(n->get("scale"), sc)) return fail("Noise: scale"); return b.noise(sc, rng); }
+        return fail("unknown texture type '" + t + "'");
+    }
+    int tex_or_color(const YNode* m, const char* color_key) {      // {texture: ...} wins over {<color_key>: {x, y, z}}
+        if (m->get("texture")) return texture(m->get("texture"));
+        Vec3 c;
+        if (!get_vec(m->get(color_key), c)) return fail(std::string("material: ") + color_key);
+        return b.solid_color(c);
+    }
+    int material(const YNode* m) {
+        if (!m || m->kind != YNode::Map) return fail("material: expected a mapping");
+        std::string t = type_of(m, "");
+        Vec3 c; double f;
+        if (t == "Lambertian") { int x = tex_or_color(m, "albedo"); return x < 0 ? -1 : b.lambertian_from_texture(x); }
+        if (t == "Metal") { if (!get_vec(m->get("albedo"), c) || !get_f64(m->get("fuzz"), f)) return fail("Metal: albedo, fuzz"); return b.metal(c, f); }
+        if (t == "Dielectric") { if (!get_f64(m->get("ir"), f)) return fail("Dielectric: ir"); return b.dielectric(f); }
+        if (t == "DiffuseLight") { int x = tex_or_color(m, "color"); return x < 0 ? -1 : b.diffuse_light(x); }
+        if (t == "Isotropic") { int x = tex_or_color(m, "albedo"); return x < 0 ? -1 : b.isotropic(x); }
+        return fail("unknown material type '" + t + "'");
+    }
+    int list(const YNode* seq) {
+        if (!seq || seq->kind != YNode::Seq) return fail("objects: expected a sequence");
+        std::vector<HittableObj> kids;
+        for (auto& item : seq->seq) { int o = object(item.get()); if (o < 0) return -1; kids.push_back(o); }
+        return b.list(kids);
+    }
+    int object(const YNode* n) {
+        if (!n || n->kind != YNode::Map) return fail("object: expected a mapping");
+        std::string t = type_of(n, "Sphere");
+        Vec3 a, c; double r, t0, t1;
+        if (t == "Sphere") {
+            if (!get_vec(n->get("center"), a) || !get_f64(n->get("radius"), r)) return fail("Sphere: center, radius");
+            int m = material(n->get("material")); return m < 0 ? -1 : b.sphere(a, r, m);
+        }
+        if (t == "MovingSphere") {
+            if (!get_vec(n->get("center0"), a) || !get_vec(n->get("center1"), c) || !get_f64(n->get("time0"), t0) ||
+                !get_f64(n->get("time1"), t1) || !get_f64(n->get("radius"), r)) return fail("MovingSphere: center0, center1, time0, time1, radius");
+            int m = material(n->get("material")); return m < 0 ? -1 : b.moving_sphere(a, c, t0, t1, r, m);
+        }
+        if (t == "Rectangle") {
+            double x0, x1, y0, y1, k;
+            const YNode* pl = n->get("plane");
+            if (!pl || pl->kind != YNode::Scalar || !get_f64(n->get("x0"), x0) || !get_f64(n->get("x1"), x1) || !get_f64(n->get("y0"), y0) ||
+                !get_f64(n->get("y1"), y1) || !get_f64(n->get("k"), k)) return fail("Rectangle: plane, x0, x1, y0, y1, k");
+            RectangleType rt_ = pl->scalar == "Xy" ? Xy : pl->scalar == "Xz" ? Xz : Yz;
+            if (pl->scalar != "Xy" && pl->scalar != "Xz" && pl->scalar != "Yz") return fail("Rectangle: plane must be Xy, Xz or Yz");
+            int m = material(n->get("material")); return m < 0 ? -1 : b.rectangle(m, x0, x1, y0, y1, k, rt_);
+        }
+        if (t == "Box") {
+            if (!get_vec(n->get("min"), a) || !get_vec(n->get("max"), c)) return fail("Box: min, max");
+            int m = material(n->get("material")); return m < 0 ? -1 : b.box(a, c, m);
+        }
+        if (t == "Translate") {
+            if (!get_vec(n->get("offset"), a)) return fail("Translate: offset");
+            int o = object(n->get("object")); return o < 0 ? -1 : b.translate(o, a);
+        }
+        if (t == "RotateY") {
+            if (!get_f64(n->get("angle_deg"), r)) return fail("RotateY: angle_deg");
+            int o = object(n->get("object")); return o < 0 ? -1 : b.rotate_y(o, r);
+        }
+        if (t == "ConstantMedium") {
+            if (!get_f64(n->get("density"), r)) return fail("ConstantMedium: density");
+            int o = object(n->get("boundary")); if (o < 0) return -1;
+            int x = texture(n->get("albedo")); return x < 0 ? -1 : b.constant_medium(o, r, x);
+        }
+        if (t == "List") return list(n->get("objects"));
+        return fail("unknown object type '" + t + "'");
+    }
+};
 
 }  // namespace
+
+HittableObj list_scene_from_yaml(Builder& b, const std::string& text, SceneRng& rng) {
+    Parser p(text);
+    std::shared_ptr<YNode> root;
+    if (p.err.empty()) root = p.parse_node(p.lines.empty() ? 0 : p.lines[0].indent);
+    if (!p.err.empty() || !root || root->kind != YNode::Map) { b.error = "Could not read values."; return -1; }
+    const YNode* scene = root->get("scene");
+    const YNode* objs = scene ? scene->get("objects") : (root->get("objects") ? root->get("objects")->get("objects") : nullptr);
+    SceneReader rd(b, rng);
+    int w = rd.list(objs);
+    if (w < 0) b.error = "Could not read values. (scene.objects: " + (rd.err.empty() ? b.error : rd.err) + ")";
+    return w;
+}
+
+// A List scene is built once into a scratch builder so that a bad object is reported when the config is read.
+static bool check_list(const std::string& text, Config& cfg, std::string& err) {
+    Builder scratch; SceneRng rng(0);
+    int w = list_scene_from_yaml(scratch, text, rng);
+    if (w < 0) { err = scratch.error; return false; }
+    cfg.n_list_objects = (int)scratch.objects[w].children.size();
+    return true;
+}
 
 bool parse_config(const std::string& text, Config& cfg, std::string& err) {
     Parser p(text);
@@ -169,6 +271,7 @@ bool parse_config(const std::string& text, Config& cfg, std::string& err) {
         err = "Could not read values." + (p.err.empty() ? std::string() : " (" + p.err + ")"); return false;  // main.rs:512
     }
     cfg = Config();
+    cfg.source = text;
     long long iv;
     if (root->get("image_width")) { if (!get_int(root->get("image_width"), iv)) { err = "Could not read values. (image_width)"; return false; } cfg.image_width = (int)iv; }
     if (root->get("samples_per_pixel")) { if (!get_int(root->get("samples_per_pixel"), iv)) { err = "Could not read values. (samples_per_pixel)"; return false; } cfg.samples_per_pixel = (int)iv; }
@@ -180,6 +283,11 @@ bool parse_config(const std::string& text, Config& cfg, std::string& err) {
         !get_f64(cam->get("focus_distance"), cfg.camera.focus_distance)) {
         err = "Could not read values. (camera)"; return false;
     }
+    // Not in the reference's schema (its TODOs at main.rs:533-534, 544): background colour and shutter interval.
+    Vec3 bg;
+    if (root->get("background")) { if (!get_vec(root->get("background"), bg)) { err = "Could not read values. (background)"; return false; } cfg.background = bg; }
+    if (cam->get("shutter_open") && !get_f64(cam->get("shutter_open"), cfg.shutter_open)) { err = "Could not read values. (camera.shutter_open)"; return false; }
+    if (cam->get("shutter_close") && !get_f64(cam->get("shutter_close"), cfg.shutter_close)) { err = "Could not read values. (camera.shutter_close)"; return false; }
     const YNode* scene = root->get("scene");  // main.rs:483-494, internally tagged by "type"
     if (scene) {
         const YNode* ty = scene->get("type");
@@ -188,12 +296,13 @@ bool parse_config(const std::string& text, Config& cfg, std::string& err) {
         static const char* known[] = {"Random", "TwoSpheres", "TwoPerlinSpheres", "SimpleLight", "Cornell", "CornellSmoke", "FinalScene", "List"};
         bool ok = false; for (const char* k : known) ok = ok || cfg.scene_type == k;
         if (!ok) { err = "Could not read values. (unknown scene type '" + cfg.scene_type + "')"; return false; }
-        if (cfg.scene_type == "List" && !get_spheres(scene->get("objects"), cfg.objects)) { err = "Could not read values. (scene.objects)"; return false; }
+        if (cfg.scene_type == "List" && !check_list(text, cfg, err)) return false;
     } else if (const YNode* legacy = root->get("objects")) {
         // Older schema of configs/orig_img.yml: top-level `objects: {objects: [...]}` and no `scene:`.
         // The reference at HEAD rejects it (missing field `scene`); it is accepted here as a List scene.
         cfg.scene_type = "List";
-        if (!get_spheres(legacy->get("objects"), cfg.objects)) { err = "Could not read values. (objects)"; return false; }
+        (void)legacy;
+        if (!check_list(text, cfg, err)) return false;
     } else { err = "Could not read values. (missing field `scene`)"; return false; }
     return true;
 }

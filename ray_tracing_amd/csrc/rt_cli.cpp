@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
     std::string config, output = "./image.ppm", checkpoint;
     long long pass_spp = 1024;
     long long spp_override = -1; unsigned long long seed = 0x5EED0002ull, scene_seed = 0x5EED0001ull; int device = 0;
-    float bg[3] = {0, 0, 0};
+    float bg[3] = {0, 0, 0}; bool bg_given = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&](const char* flag) -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "rt_cli: %s needs a value\n", flag); std::exit(2); } return argv[++i]; };
@@ -34,7 +34,7 @@ int main(int argc, char** argv) {
         else if (a == "--device") device = std::atoi(next("--device"));
         else if (a == "--checkpoint") checkpoint = next("--checkpoint");
         else if (a == "--pass-spp") pass_spp = std::max(1LL, std::atoll(next("--pass-spp")));
-        else if (a == "--background") { if (std::sscanf(next("--background"), "%f,%f,%f", &bg[0], &bg[1], &bg[2]) != 3) { std::fprintf(stderr, "rt_cli: --background r,g,b\n"); return 2; } }
+        else if (a == "--background") { if (std::sscanf(next("--background"), "%f,%f,%f", &bg[0], &bg[1], &bg[2]) != 3) { std::fprintf(stderr, "rt_cli: --background r,g,b\n"); return 2; } bg_given = true; }
         else { std::fprintf(stderr, "usage: rt_cli -c <config.yml> [-o <image.ppm>] [--spp N] [--seed N] [--scene-seed N] [--device N] [--background r,g,b] [--checkpoint <file>] [--pass-spp N]\n"); return 2; }
     }
     if (config.empty()) { std::fprintf(stderr, "rt_cli: the following required arguments were not provided: --config <CONFIG>\n"); return 2; }
@@ -51,7 +51,8 @@ int main(int argc, char** argv) {
     std::memcpy(cam.look_from, cfg.look_from, sizeof(cam.look_from)); std::memcpy(cam.look_at, cfg.look_at, sizeof(cam.look_at));
     std::memcpy(cam.v_up, cfg.v_up, sizeof(cam.v_up));
     cam.vertical_fov_deg = cfg.vertical_fov_deg; cam.aspect_ratio = cfg.aspect_ratio; cam.aperture = cfg.aperture; cam.focus_dist = cfg.focus_distance;
-    cam.shutter_open = 0.0; cam.shutter_close = 1.0;  // main.rs:544-546
+    cam.shutter_open = cfg.shutter_open; cam.shutter_close = cfg.shutter_close;  // 0 and 1 unless the config says otherwise (main.rs:544-546)
+    if (!bg_given) std::memcpy(bg, cfg.background, sizeof(bg));
     RtRenderParams p; std::memset(&p, 0, sizeof(p));
     p.width = cfg.image_width; p.height = cfg.image_height; p.spp = spp_override > 0 ? (int)spp_override : cfg.samples_per_pixel;
     p.max_depth = cfg.max_depth; p.seed = seed; std::memcpy(p.background, bg, sizeof(bg));

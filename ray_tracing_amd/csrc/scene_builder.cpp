@@ -302,13 +302,8 @@ HittableObj canned_scene(Builder& b, const std::string& type, uint64_t seed) {  
 
 HittableObj scene_from_config(Builder& b, const Config& cfg, uint64_t seed) {
     if (cfg.scene_type != "List") return canned_scene(b, cfg.scene_type, seed);
-    std::vector<HittableObj> w;  // objects.rs:56-63, 170-176; materials.rs:45-51
-    for (const SphereConfig& s : cfg.objects) {
-        Material m = s.mat_type == RT_MAT_LAMBERTIAN ? b.lambertian(s.albedo)
-                   : s.mat_type == RT_MAT_METAL ? b.metal(s.albedo, s.fuzz) : b.dielectric(s.ir);
-        w.push_back(b.sphere(s.center, s.radius, m));
-    }
-    return b.list(w);
+    SceneRng rng(seed);                      // objects.rs:56-63, 170-176; materials.rs:45-51, and the typed items of config.cpp
+    return list_scene_from_yaml(b, cfg.source, rng);
 }
 
 // ------------------------------------------------------------------ camera (cameras.rs:38-79)

@@ -107,12 +107,14 @@ HittableObj canned_scene(Builder& b, const std::string& type, uint64_t scene_see
 
 // ---- Config (main.rs:453-494, cameras.rs:10-18, objects.rs:104-107,248-253, materials.rs:34-40)
 struct CameraConfig { Vec3 look_from, look_at, v_up; double vertical_fov_deg, aspect_ratio, aperture, focus_distance; };
-struct SphereConfig { Vec3 center; double radius; int mat_type; Vec3 albedo; double fuzz, ir; };
 struct Config {
     int image_width = 400, samples_per_pixel = 500, max_depth = 50;   // main.rs:468-480
     CameraConfig camera;
+    double shutter_open = 0.0, shutter_close = 1.0;   // main.rs:544-545 hard-codes 0 and 1; optional camera keys here
+    Vec3 background = {0.0, 0.0, 0.0};                // main.rs:534 hard-codes black; optional top-level key here
     std::string scene_type;                 // Random | TwoSpheres | ... | List
-    std::vector<SphereConfig> objects;      // scene_type == "List"
+    std::string source;                     // the YAML text (a List scene is built from it)
+    int n_list_objects = 0;                 // top-level items of a List scene
     int image_height() const;               // main.rs:515-516
 };
 // Parses the YAML subset the reference's configs use.  Returns false and sets err on failure
@@ -120,6 +122,8 @@ struct Config {
 bool load_config(const std::string& path, Config& out, std::string& err);
 bool parse_config(const std::string& text, Config& out, std::string& err);
 HittableObj scene_from_config(Builder& b, const Config& cfg, uint64_t scene_seed);
+// The `objects` of a List scene (the reference's spheres-only form and the typed items described in config.cpp).
+HittableObj list_scene_from_yaml(Builder& b, const std::string& yaml_text, SceneRng& rng);
 
 // ---- Camera (cameras.rs:38-79), evaluated in f64 on the host
 struct CameraDesc {

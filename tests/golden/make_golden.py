@@ -16,7 +16,7 @@ import helpers  # noqa: E402
 
 CASES = [("orig_img.yml", 48, 8, (0.7, 0.8, 1.0)), ("rectangle.yml", 48, 8, (0, 0, 0)), ("cfg.yml", 48, 4, (0.7, 0.8, 1.0)),
          ("two_spheres.yml", 48, 4, (0.7, 0.8, 1.0)), ("random.yml", 48, 4, (0.7, 0.8, 1.0)), ("cornell_box.yml", 40, 8, (0, 0, 0)),
-         ("cornell.yml", 40, 8, (0, 0, 0)), ("final_scene.yml", 40, 8, (0, 0, 0))]
+         ("cornell.yml", 40, 8, (0, 0, 0)), ("final_scene.yml", 40, 8, (0, 0, 0)), ("showcase.yml", 48, 8, (0.02, 0.03, 0.06))]
 
 
 def make(name, width, spp, background):
@@ -31,7 +31,10 @@ def make(name, width, spp, background):
 
 
 if __name__ == "__main__":
+    only = sys.argv[1:]
     for name, width, spp, bg in CASES:
+        if only and name not in only:
+            continue
         out = os.path.join(HERE, name.replace(".yml", ".npz"))
         np.savez_compressed(out, **make(name, width, spp, bg))
         print(out, os.path.getsize(out))

@@ -92,10 +92,11 @@ def emul():
     if _emul is None:
         csrc = os.path.join(ROOT, "ray_tracing_amd", "csrc")
         srcs = [os.path.join(ROOT, "tests", "emul", "rt_emul.cpp")] + [os.path.join(csrc, f) for f in
-                                                                      ("rt_device.h", "rt_types.h", "scene_builder.cpp", "scene_builder.h")]
+                                                                      ("rt_device.h", "rt_types.h", "scene_builder.cpp", "scene_builder.h", "config.cpp")]
         _build_if_stale(EMUL_SO, srcs,
                         ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wno-unknown-pragmas",
-                         "-o", EMUL_SO, srcs[0], os.path.join(csrc, "scene_builder.cpp")], os.path.join(ROOT, "tests", "emul"))
+                         "-o", EMUL_SO, srcs[0], os.path.join(csrc, "scene_builder.cpp"), os.path.join(csrc, "config.cpp")],
+                        os.path.join(ROOT, "tests", "emul"))
         L = C.CDLL(EMUL_SO)
         L.emul_trace_primary.argtypes = [_P, C.POINTER(rt.RtCamera), C.POINTER(rt.RtRenderParams), C.c_int32, _P, _P, _P, _P, _P]
         L.emul_render.argtypes = [_P, C.POINTER(rt.RtCamera), C.POINTER(rt.RtRenderParams), C.c_int, _P, _P, C.POINTER(C.c_uint64)]
@@ -258,6 +259,79 @@ def config_camera(name):
     return cfg, rt.camera_from_config(cfg)
 
 
+class SplitMix:
+    """The scene-construction stream (SplitMix64), restated for the YAML mirror below."""
+    M = (1 << 64) - 1
+
+    def __init__(self, seed):
+        self.s = seed & self.M
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & self.M
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & self.M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & self.M
+        return z ^ (z >> 31)
+
+    def gen(self): return (self.next() >> 11) * (1.0 / 9007199254740992.0)
+    def range(self, a, b): return a + (b - a) * self.gen()
+    def upto(self, i): return self.next() % (i + 1)
+
+
+def yaml_list(ob, items, rng):
+    """Builds the `objects` of a List scene on the oracle from the PyYAML document: an independent reading of the schema
+    that ray_tracing_amd/csrc/config.cpp implements (the reference's sphere items plus the typed items)."""
+    v = lambda d: (d["x"], d["y"], d["z"])
+
+    def texture(t):
+        if "type" not in t:
+            return ob.solid_color(v(t))
+        if t["type"] == "SolidColor":
+            return ob.solid_color(v(t["color"]))
+        if t["type"] == "Checker":
+            e = texture(t["even"]); o = texture(t["odd"])
+            return ob.checker(e, o)
+        if t["type"] == "Noise":          # textures.rs:110-128: 256 vectors in [-1, 1)^3, then three Fisher-Yates permutations
+            ranvec = [[rng.range(-1.0, 1.0) for _ in range(3)] for _ in range(256)]
+            perms = []
+            for _ in range(3):
+                p = list(range(256))
+                for i in range(255, 0, -1):
+                    j = rng.upto(i); p[i], p[j] = p[j], p[i]
+                perms.append(p)
+            return ob.noise(t["scale"], ranvec, perms)
+        raise ValueError(t["type"])
+
+    def tex_or_color(m, key):
+        return texture(m["texture"]) if "texture" in m else ob.solid_color(v(m[key]))
+
+    def material(m):
+        t = m["type"]
+        if t == "Lambertian": return ob.lambertian_from_texture(tex_or_color(m, "albedo"))
+        if t == "Metal": return ob.metal(v(m["albedo"]), m["fuzz"])
+        if t == "Dielectric": return ob.dielectric(m["ir"])
+        if t == "DiffuseLight": return ob.diffuse_light(tex_or_color(m, "color"))
+        if t == "Isotropic": return ob.isotropic(tex_or_color(m, "albedo"))
+        raise ValueError(t)
+
+    def obj(o):
+        t = o.get("type", "Sphere")
+        if t == "Sphere": return ob.sphere(v(o["center"]), o["radius"], material(o["material"]))
+        if t == "MovingSphere":
+            return ob.moving_sphere(v(o["center0"]), v(o["center1"]), o["time0"], o["time1"], o["radius"], material(o["material"]))
+        if t == "Rectangle":
+            return ob.rectangle(material(o["material"]), o["x0"], o["x1"], o["y0"], o["y1"], o["k"], {"Xy": 0, "Xz": 1, "Yz": 2}[o["plane"]])
+        if t == "Box": return ob.box(v(o["min"]), v(o["max"]), material(o["material"]))
+        if t == "Translate": return ob.translate(obj(o["object"]), v(o["offset"]))
+        if t == "RotateY": return ob.rotate_y(obj(o["object"]), o["angle_deg"])
+        if t == "ConstantMedium":
+            bnd = obj(o["boundary"])
+            return ob.constant_medium(bnd, o["density"], texture(o["albedo"]))
+        if t == "List": return yaml_list(ob, o["objects"], rng)
+        raise ValueError(t)
+    return ob.list([obj(o) for o in items])
+
+
 def scene_pair(name, scene_seed=SCENE_SEED):
     """Builds configs/<name> on the product builder and the same scene on the oracle.  Returns (cfg, cam, builder, world, oracle_builder)."""
     import yaml
@@ -270,18 +344,7 @@ def scene_pair(name, scene_seed=SCENE_SEED):
     if stype == "List":
         doc = yaml.safe_load(open(path))
         objs = (doc.get("scene") or doc["objects"])["objects"]
-        kids = []
-        for o in objs:
-            m = o["material"]
-            v = lambda d: (d["x"], d["y"], d["z"])
-            if m["type"] == "Lambertian":
-                mat = ob.lambertian(v(m["albedo"]))
-            elif m["type"] == "Metal":
-                mat = ob.metal(v(m["albedo"]), m["fuzz"])
-            else:
-                mat = ob.dielectric(m["ir"])
-            kids.append(ob.sphere(v(o["center"]), o["radius"], mat))
-        ow = ob.list(kids)
+        ow = yaml_list(ob, objs, SplitMix(scene_seed))
     else:
         ow = ob.canned_scene(stype, scene_seed)
     ob.set_world(ow, True)

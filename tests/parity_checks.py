@@ -9,7 +9,7 @@ import ctypes as C
 from helpers import RENDER_SEED, OracleBuilder, OracleCamera, d3, oracle, oracle_render, oracle_trace_primary, primary_agreement
 
 SKY = (0.7, 0.8, 1.0)   # the commented-out background of main.rs:533; scenes without lights render black otherwise
-BACKGROUND = {"orig_img.yml": SKY, "cfg.yml": SKY, "two_spheres.yml": SKY, "random.yml": SKY}
+BACKGROUND = {"orig_img.yml": SKY, "cfg.yml": SKY, "two_spheres.yml": SKY, "random.yml": SKY, "showcase.yml": (0.02, 0.03, 0.06)}
 
 ID_AGREEMENT = 0.9999    # primary-hit object ids must be equal on >= 99.99 % of the pixels
 T_REL_TOL = 1e-4         # |t_gpu - t_oracle| <= 1e-4 |t_oracle| on every agreeing pixel (fp32 vs the reference's f64)

@@ -212,3 +212,29 @@ def test_png_and_ppm_writers_and_checkpoints(tmp_path):
     assert np.array_equal(got, acc) and spp == 1234 and seed == 0x5EED0002
     with pytest.raises(rt.RtError):
         rt.accum_load(ck, 53, 37)                      # a checkpoint of another image size is refused
+
+
+def test_extended_list_schema(tmp_path):
+    """Typed List items (every constructor of the prelude), optional background and shutter keys, and their error reports."""
+    cfg = rt.load_config(os.path.join(CONFIGS, "showcase.yml"))
+    assert cfg.scene_type == b"List" and cfg.n_list_objects == 10 and (cfg.image_width, cfg.image_height) == (480, 320)
+    assert (cfg.shutter_open, cfg.shutter_close) == (0.0, 0.5) and np.allclose(list(cfg.background), [0.02, 0.03, 0.06])
+    cam = rt.camera_from_config(cfg)
+    assert cam.shutter_close == 0.5
+    b = rt.Builder()
+    info = b.flatten_info(b.scene_from_config(os.path.join(CONFIGS, "showcase.yml"), SCENE_SEED))
+    # ground, noise, glass, metal, 2 small spheres + the medium's boundary sphere; a moving sphere; 2 rects; a box under RotateY + Translate
+    assert (info.n_spheres, info.n_moving_spheres, info.n_rects, info.n_boxes, info.n_instances, info.n_media, info.n_perlin) == (7, 1, 2, 1, 1, 1, 1)
+    old = rt.load_config(os.path.join(CONFIGS, "orig_img.yml"))           # the reference's own item form still reads as before
+    assert old.n_list_objects == 5 and (old.shutter_open, old.shutter_close) == (0.0, 1.0) and list(old.background) == [0, 0, 0]
+    head = "camera: {look_from: {x: 0, y: 0, z: 1}, look_at: {x: 0, y: 0, z: 0}, v_up: {x: 0, y: 1, z: 0}, vertical_fov_deg: 20, aspect_ratio: 1, aperture: 0, focus_distance: 1}\n"
+    bad = {"unknown object type 'Torus'": "scene:\n  type: List\n  objects:\n    - {type: Torus, radius: 1}\n",
+           "Rectangle: plane": "scene:\n  type: List\n  objects:\n    - {type: Rectangle, x0: 0, x1: 1, y0: 0, y1: 1, k: 0, material: {type: Dielectric, ir: 1.5}}\n",
+           "unknown material type 'Plastic'": "scene:\n  type: List\n  objects:\n    - {center: {x: 0, y: 0, z: 0}, radius: 1, material: {type: Plastic}}\n",
+           "background": "background: blue\nscene: {type: TwoSpheres}\n"}
+    for msg, text in bad.items():
+        path = tmp_path / "bad.yml"
+        path.write_text(head + text)
+        with pytest.raises(rt.RtError) as e:
+            rt.load_config(str(path))
+        assert e.value.code == -7 and "Could not read values." in str(e.value) and msg in str(e.value), (msg, str(e.value))

@@ -10,7 +10,7 @@ import pytest
 from helpers import GOLDEN, FlatScene, emul, emul_render, emul_trace_primary, oracle, scene_pair
 from parity_checks import BACKGROUND, check_golden, check_primary, check_render, check_scatter_events
 
-ALL = ["orig_img.yml", "rectangle.yml", "cfg.yml", "two_spheres.yml", "random.yml", "cornell_box.yml", "cornell.yml", "final_scene.yml"]
+ALL = ["orig_img.yml", "rectangle.yml", "cfg.yml", "two_spheres.yml", "random.yml", "cornell_box.yml", "cornell.yml", "final_scene.yml", "showcase.yml"]
 
 
 class EmulBackend:

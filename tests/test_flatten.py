@@ -85,7 +85,7 @@ def walk(a, node, seen, depth, stats, in_blas):
     return out_lo, out_hi
 
 
-@pytest.mark.parametrize("name", ["orig_img.yml", "rectangle.yml", "random.yml", "cornell_box.yml", "cornell.yml", "final_scene.yml"])
+@pytest.mark.parametrize("name", ["orig_img.yml", "rectangle.yml", "random.yml", "cornell_box.yml", "cornell.yml", "final_scene.yml", "showcase.yml"])
 def test_bvh_invariants(name):
     cfg, cam, b, world, ob = scene_pair(name)
     flat = FlatScene(b, world)

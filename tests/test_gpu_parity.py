@@ -12,7 +12,7 @@ from helpers import CONFIGS, GOLDEN, RENDER_SEED, SCENE_SEED, OracleBuilder, Ora
 from parity_checks import BACKGROUND, check_golden, check_primary, check_render, check_scatter_events
 
 pytestmark = pytest.mark.gpu
-ALL = ["orig_img.yml", "rectangle.yml", "cfg.yml", "two_spheres.yml", "random.yml", "cornell_box.yml", "cornell.yml", "final_scene.yml"]
+ALL = ["orig_img.yml", "rectangle.yml", "cfg.yml", "two_spheres.yml", "random.yml", "cornell_box.yml", "cornell.yml", "final_scene.yml", "showcase.yml"]
 
 
 class GpuBackend:
