@@ -767,7 +767,14 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     int chunk_max = (int)std::max<size_t>(1, target / n_pixels);
     if ((size_t)chunk_max * n_pixels > 0xFFFFFFF0ull) chunk_max = (int)(0xFFFFFFF0ull / n_pixels);
     chunk_max = std::min(chunk_max, std::max(1, p->spp));
-    if ((rc = ensure_workspace(s, (size_t)chunk_max * n_pixels))) return rc;
+    // The default pass is sized for an otherwise empty 288 GB part; when the workspace does not fit (other tenants, several
+    // scene handles) the pass is halved until it does.  An explicit paths_per_pass is taken as given.
+    while ((rc = ensure_workspace(s, (size_t)chunk_max * n_pixels)) == RT_ERR_OOM && p->paths_per_pass <= 0 && chunk_max > 1) {
+        free_workspace(s);
+        (void)hipGetLastError();
+        chunk_max = (chunk_max + 1) / 2;
+    }
+    if (rc) return rc;
 
     RtStats local; std::memset(&local, 0, sizeof(local));
     local.paths = (uint64_t)n_pixels * (uint64_t)p->spp;
