@@ -229,6 +229,12 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, 
             } else {
                 do {
                     if (STATS) { unsigned long long ex = __ballot(true); if ((int)lane == __ffsll((long long)ex) - 1) dbg[3]++; }
+#ifdef RT_LEAF_TWICE   /* timing experiment: the leaf step run twice with the same result */
+                    { RtTrav t2 = tv; RtHit h2 = hit;
+                      rt_leaf_step<false>(prims, wo, wd, time, RT_TMIN, src, t2, h2, stk, &cnt);
+                      asm volatile("" : "+v"(wo.x), "+v"(wd.x), "+v"(h2.t));
+                      if (h2.t < 0.0f) hit.t = h2.t; }
+#endif
                     rt_leaf_step<STATS>(prims, wo, wd, time, RT_TMIN, src, tv, hit, stk, &cnt);
                 } while (tv.cur < 0);
             }

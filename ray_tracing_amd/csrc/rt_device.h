@@ -201,12 +201,13 @@ RT_HD float rt_hit_sphere(v3 c, float r, v3 o, v3 d, float tmin, float tmax, boo
 
 // Rectangle (objects.rs:384-411).  type 0 = Xy, 1 = Xz, 2 = Yz.  A NaN t (ray inside the plane
 // with a zero direction component) is a miss here; the reference's comparisons let it through.
-RT_HD float rt_hit_rect(rt_f4 r0, float k, int type, v3 o, v3 d, float tmin, float tmax) {
-    float oa, da, ox, dx, oy, dy;
-    if (type == 0) { oa = o.z; da = d.z; ox = o.x; dx = d.x; oy = o.y; dy = d.y; }
-    else if (type == 1) { oa = o.y; da = d.y; ox = o.x; dx = d.x; oy = o.z; dy = d.z; }
-    else { oa = o.x; da = d.x; ox = o.y; dx = d.y; oy = o.z; dy = d.z; }
-    float t = (k - oa) * rt_rcp(da);
+// `inv` = (1/d.x, 1/d.y, 1/d.z) as rt_rcp gives them: callers that traverse already hold it.
+RT_HD float rt_hit_rect(rt_f4 r0, float k, int type, v3 o, v3 d, v3 inv, float tmin, float tmax) {
+    float oa, ia, ox, dx, oy, dy;
+    if (type == 0) { oa = o.z; ia = inv.z; ox = o.x; dx = d.x; oy = o.y; dy = d.y; }
+    else if (type == 1) { oa = o.y; ia = inv.y; ox = o.x; dx = d.x; oy = o.z; dy = d.z; }
+    else { oa = o.x; ia = inv.x; ox = o.y; dx = d.y; oy = o.z; dy = d.z; }
+    float t = (k - oa) * ia;
     if (!(t >= tmin && t <= tmax)) return rt_nan();
     float x = fmaf(t, dx, ox), y = fmaf(t, dy, oy);
     if (x < r0.x || x > r0.y || y < r0.z || y > r0.w) return rt_nan();
@@ -218,8 +219,8 @@ RT_HD float rt_hit_rect(rt_f4 r0, float k, int type, v3 o, v3 d, float tmin, flo
 // (k - o[a]) / d[a] is the very expression of the rectangle test (objects.rs:390).  Returns the accepted t (NaN:
 // none) and the side index in `face` (0..5 = z max, z min, y max, y min, x max, x min).  `skip` = side the ray
 // starts on (-1: none), which a ray can never re-hit.
-RT_HD bool rt_box_slabs(rt_f4 b0, rt_f4 b1, v3 o, v3 d, float& t_in, float& t_out, int& f_in, int& f_out) {
-    float ix = rt_rcp(d.x), iy = rt_rcp(d.y), iz = rt_rcp(d.z);
+RT_HD bool rt_box_slabs(rt_f4 b0, rt_f4 b1, v3 o, v3 d, v3 inv, float& t_in, float& t_out, int& f_in, int& f_out) {
+    float ix = inv.x, iy = inv.y, iz = inv.z;
     float x0 = (b0.x - o.x) * ix, x1 = (b1.x - o.x) * ix;
     float y0 = (b0.y - o.y) * iy, y1 = (b1.y - o.y) * iy;
     float z0 = (b0.z - o.z) * iz, z1 = (b1.z - o.z) * iz;
@@ -231,9 +232,9 @@ RT_HD bool rt_box_slabs(rt_f4 b0, rt_f4 b1, v3 o, v3 d, float& t_in, float& t_ou
     f_out = t_out == lz ? (d.z > 0.0f ? 0 : 1) : (t_out == ly ? (d.y > 0.0f ? 2 : 3) : (d.x > 0.0f ? 4 : 5));
     return t_in <= t_out;
 }
-RT_HD float rt_hit_box(rt_f4 b0, rt_f4 b1, v3 o, v3 d, float tmin, float tmax, int skip, int& face) {
+RT_HD float rt_hit_box(rt_f4 b0, rt_f4 b1, v3 o, v3 d, v3 inv, float tmin, float tmax, int skip, int& face) {
     float t_in, t_out; int f_in, f_out;
-    if (!rt_box_slabs(b0, b1, o, d, t_in, t_out, f_in, f_out)) return rt_nan();
+    if (!rt_box_slabs(b0, b1, o, d, inv, t_in, t_out, f_in, f_out)) return rt_nan();
     if (t_in >= tmin && t_in <= tmax && f_in != skip) { face = f_in; return t_in; }
     if (t_out >= tmin && t_out <= tmax && f_out != skip) { face = f_out; return t_out; }
     return rt_nan();
@@ -371,14 +372,14 @@ RT_HD void rt_leaf_step(const Prims& prims, v3 wo, v3 wd, float time, float tmin
             rt_f4 b0, b1;
             prims.box(idx, b0, b1);
             int skip = (src >> 3) == (RT_HIT_CODE(RT_KIND_BOX, idx << 3) >> 3) ? (int)(src & 7u) : -1, face = 0;
-            t = rt_hit_box(b0, b1, tv.o, tv.d, tmin, hit.t, skip, face);
+            t = rt_hit_box(b0, b1, tv.o, tv.d, tv.inv, tmin, hit.t, skip, face);
             code = RT_HIT_CODE(RT_KIND_BOX, (idx << 3) | (uint32_t)face);
         } else if (kind == RT_KIND_RECT) {
             if (STATS) wc->rects++;
             if (code == src) continue;
             rt_f4 r0, r1;
             prims.rect(idx, r0, r1);
-            t = rt_hit_rect(r0, r1.x, f2i(r1.y), tv.o, tv.d, tmin, hit.t);
+            t = rt_hit_rect(r0, r1.x, f2i(r1.y), tv.o, tv.d, tv.inv, tmin, hit.t);
         } else {  // sphere or moving sphere: one intersection path, the centre is the only difference
             v3 c; float r;
             if (kind == RT_KIND_SPHERE) {
@@ -425,6 +426,7 @@ RT_HD void rt_closest_hit(const RtSceneView& sc, v3 wo, v3 wd, float time, float
 // Closest hit of the boundary's primitives inside [tmin, tmax] (linear scan = objects.rs:67-78).
 RT_HD float rt_boundary_hit(const RtSceneView& sc, rt_f4 m2, rt_f4 m3, rt_f4 m4, v3 o, v3 d, float time, float tmin, float tmax) {
     float best = tmax; bool any = false;
+    const v3 inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
     int s0 = rt_uniform(f2i(m2.y)), sn = rt_uniform(f2i(m2.z)), q0 = rt_uniform(f2i(m2.w)), qn = rt_uniform(f2i(m3.x));
     int r0 = rt_uniform(f2i(m3.y)), rn = rt_uniform(f2i(m3.z));
     for (int i = 0; i < sn; ++i) {
@@ -440,14 +442,14 @@ RT_HD float rt_boundary_hit(const RtSceneView& sc, rt_f4 m2, rt_f4 m3, rt_f4 m4,
     }
     for (int i = 0; i < rn; ++i) {
         rt_f4 a = ld4(sc.rects + 2 * (size_t)(r0 + i)), b = ld4(sc.rects + 2 * (size_t)(r0 + i) + 1);
-        float t = rt_hit_rect(a, b.x, f2i(b.y), o, d, tmin, best);
+        float t = rt_hit_rect(a, b.x, f2i(b.y), o, d, inv, tmin, best);
         if (t == t) { best = t; any = true; }
     }
     int x0 = rt_uniform(f2i(m4.x)), xn = rt_uniform(f2i(m4.y));
     for (int i = 0; i < xn; ++i) {
         rt_f4 a = ld4(sc.boxes + 2 * (size_t)(x0 + i)), b = ld4(sc.boxes + 2 * (size_t)(x0 + i) + 1);
         int face;
-        float t = rt_hit_box(a, b, o, d, tmin, best, -1, face);
+        float t = rt_hit_box(a, b, o, d, inv, tmin, best, -1, face);
         if (t == t) { best = t; any = true; }
     }
     return any ? best : rt_nan();
@@ -458,6 +460,7 @@ RT_HD float rt_boundary_hit(const RtSceneView& sc, rt_f4 m2, rt_f4 m3, rt_f4 m4,
 // the smallest crossing that is >= t1 + 0.0001, which is b unless two crossings coincide (ray through an edge).
 RT_HD void rt_boundary_pair(const RtSceneView& sc, rt_f4 m2, rt_f4 m3, rt_f4 m4, v3 o, v3 d, float time, float& a, float& b) {
     a = rt_inf(); b = rt_inf();
+    const v3 inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
     int s0 = rt_uniform(f2i(m2.y)), sn = rt_uniform(f2i(m2.z)), q0 = rt_uniform(f2i(m2.w)), qn = rt_uniform(f2i(m3.x));
     int r0 = rt_uniform(f2i(m3.y)), rn = rt_uniform(f2i(m3.z));
 #define RT_INSERT(t_) do { float t__ = (t_); if (t__ < a) { b = a; a = t__; } else if (t__ < b) b = t__; } while (0)
@@ -474,14 +477,14 @@ RT_HD void rt_boundary_pair(const RtSceneView& sc, rt_f4 m2, rt_f4 m3, rt_f4 m4,
     }
     for (int i = 0; i < rn; ++i) {
         rt_f4 ra = ld4(sc.rects + 2 * (size_t)(r0 + i)), rb = ld4(sc.rects + 2 * (size_t)(r0 + i) + 1);
-        float t = rt_hit_rect(ra, rb.x, f2i(rb.y), o, d, -rt_inf(), rt_inf());
+        float t = rt_hit_rect(ra, rb.x, f2i(rb.y), o, d, inv, -rt_inf(), rt_inf());
         if (t == t) RT_INSERT(t);
     }
     int x0 = rt_uniform(f2i(m4.x)), xn = rt_uniform(f2i(m4.y));
     for (int i = 0; i < xn; ++i) {  // a box is crossed at its entry and its exit side
         rt_f4 ba = ld4(sc.boxes + 2 * (size_t)(x0 + i)), bb = ld4(sc.boxes + 2 * (size_t)(x0 + i) + 1);
         float t_in, t_out; int f_in, f_out;
-        if (rt_box_slabs(ba, bb, o, d, t_in, t_out, f_in, f_out)) { RT_INSERT(t_in); RT_INSERT(t_out); }
+        if (rt_box_slabs(ba, bb, o, d, inv, t_in, t_out, f_in, f_out)) { RT_INSERT(t_in); RT_INSERT(t_out); }
     }
 #undef RT_INSERT
 }
@@ -527,7 +530,7 @@ RT_HD void rt_media_hits(const RtSceneView& sc, const MediaSrc& msrc, v3 wo, v3 
             } else {
                 rt_f4 p1 = msrc.get(m, 7);
                 int f_in, f_out;
-                if (!rt_box_slabs(p0, p1, o, d, t1, t2, f_in, f_out)) continue;
+                if (!rt_box_slabs(p0, p1, o, d, mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z)), t1, t2, f_in, f_out)) continue;
             }
             if (t2 < t1 + fmaxf(0.0001f, 1e-6f * fabsf(t1))) continue;                  // coincident crossings: no second one
         } else {
