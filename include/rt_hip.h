@@ -104,18 +104,26 @@ int rt_canned_scene(RtBuilder* b, const char* scene_type, uint64_t scene_seed, R
 /* Flattens the tree under `world` (BVH build included, replacing BvhNode::new of src/main.rs:531)
  * and uploads it to GPU `device`. */
 int rt_scene_create(const RtBuilder* b, RtObj world, int device, RtScene** out);
+/* flags = RT_BVH_LINEAR: the top-level BVH (what BvhNode::new of src/main.rs:531 is in the reference, src/bvh.rs:89-156) is a
+ * linear BVH built on the GPU -- Morton codes, radix sort, radix tree, bottom-up boxes -- instead of the host's binned-SAH
+ * tree: milliseconds instead of seconds for a million primitives, at the price of a slower tree to traverse.  Closest hits
+ * do not depend on the tree.  rt_flat_create_ex runs the same steps on the host. */
+#define RT_BVH_LINEAR 1
+int rt_scene_create_ex(const RtBuilder* b, RtObj world, int device, int flags, RtScene** out);
 void rt_scene_destroy(RtScene* s);
 typedef struct RtSceneInfo {
     int32_t n_nodes, n_spheres, n_moving_spheres, n_rects, n_instances, n_media, n_materials, n_textures, n_perlin;
     int32_t tlas_depth, blas_depth, max_stack, n_objects, device, n_boxes;  /* n_boxes: BoxObj kept as one 6-sided primitive */
     double world_box[6];
     uint64_t device_bytes;
+    double bvh_build_seconds;   /* RT_BVH_LINEAR scenes: device time of the top-level build */
 } RtSceneInfo;
 int rt_scene_info(const RtScene* s, RtSceneInfo* out);
 /* Host-only flatten (no GPU touched): for inspection and CPU-side checks.  The returned pointer is
  * an RtSceneView (ray_tracing_amd/csrc/rt_types.h) with HOST pointers, valid until rt_flat_destroy. */
 typedef struct RtFlat RtFlat;
 int rt_flat_create(const RtBuilder* b, RtObj world, RtFlat** out);
+int rt_flat_create_ex(const RtBuilder* b, RtObj world, int flags, RtFlat** out);
 const void* rt_flat_view(const RtFlat* f);
 int rt_flat_info(const RtFlat* f, RtSceneInfo* out);
 void rt_flat_destroy(RtFlat* f);

@@ -18,6 +18,7 @@ _lib = None
 RT_FLAG_SUMSQ = 1
 RT_FLAG_COUNTERS = 2
 RT_FLAG_TIME_TRACE = 4
+RT_BVH_LINEAR = 1            # rt_scene_create_ex / rt_flat_create_ex: linear top-level BVH (built on the GPU for a Scene)
 RECT_XY, RECT_XZ, RECT_YZ = 0, 1, 2   # RectangleType, src/objects.rs:339-343
 
 
@@ -40,7 +41,7 @@ class RtSceneInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_nodes", "n_spheres", "n_moving_spheres", "n_rects", "n_instances",
                                          "n_media", "n_materials", "n_textures", "n_perlin", "tlas_depth",
                                          "blas_depth", "max_stack", "n_objects", "device", "n_boxes")] + \
-               [("world_box", C.c_double * 6), ("device_bytes", C.c_uint64)]
+               [("world_box", C.c_double * 6), ("device_bytes", C.c_uint64), ("bvh_build_seconds", C.c_double)]
 
 
 class RtCamera(C.Structure):
@@ -91,9 +92,11 @@ API = {
     "rt_config_build_scene": (C.c_int, [C.c_char_p, C.c_uint64, _P, C.POINTER(C.c_int32)]),
     "rt_canned_scene": (C.c_int, [_P, C.c_char_p, C.c_uint64, C.POINTER(C.c_int32)]),
     "rt_scene_create": (C.c_int, [_P, C.c_int32, C.c_int, C.POINTER(_P)]),
+    "rt_scene_create_ex": (C.c_int, [_P, C.c_int32, C.c_int, C.c_int, C.POINTER(_P)]),
     "rt_scene_destroy": (None, [_P]),
     "rt_scene_info": (C.c_int, [_P, C.POINTER(RtSceneInfo)]),
     "rt_flat_create": (C.c_int, [_P, C.c_int32, C.POINTER(_P)]),
+    "rt_flat_create_ex": (C.c_int, [_P, C.c_int32, C.c_int, C.POINTER(_P)]),
     "rt_flat_view": (_P, [_P]),
     "rt_flat_info": (C.c_int, [_P, C.POINTER(RtSceneInfo)]),
     "rt_flat_destroy": (None, [_P]),
@@ -163,8 +166,8 @@ class Builder:
         _check(lib().rtb_create(C.byref(self._h)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().rtb_destroy(self._h)
+        if getattr(self, "_h", None) and _lib is not None and lib is not None:   # module globals are gone at interpreter exit
+            _lib.rtb_destroy(self._h)
             self._h = None
 
     # textures.rs
@@ -224,10 +227,10 @@ class Builder:
         _check(lib().rt_config_build_scene(path.encode(), scene_seed, self._h, C.byref(w)))
         return w.value
 
-    def flatten_info(self, world):
-        """Host-only flatten; returns RtSceneInfo (no GPU needed)."""
+    def flatten_info(self, world, flags=0):
+        """Host-only flatten; returns RtSceneInfo (no GPU needed).  flags: RT_BVH_LINEAR."""
         f = _P()
-        _check(lib().rt_flat_create(self._h, world, C.byref(f)))
+        _check(lib().rt_flat_create_ex(self._h, world, flags, C.byref(f)))
         try:
             info = RtSceneInfo()
             _check(lib().rt_flat_info(f, C.byref(info)))
@@ -276,9 +279,9 @@ def render_params(width, height, spp, max_depth, seed, sample_offset=0, backgrou
 class Scene:
     """A flattened scene resident on one GPU (rt_scene_create)."""
 
-    def __init__(self, builder, world, device=0):
+    def __init__(self, builder, world, device=0, flags=0):
         self._h = _P()
-        _check(lib().rt_scene_create(builder._h, world, device, C.byref(self._h)))
+        _check(lib().rt_scene_create_ex(builder._h, world, device, flags, C.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None):

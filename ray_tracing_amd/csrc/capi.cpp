@@ -15,11 +15,6 @@ static rt::Vec3 v3d(const double* p) { return rt::vec3(p[0], p[1], p[2]); }
 static int handle(RtBuilder* b, int h) { if (h < 0) g_rt_error = b->b.error; return h; }
 #define NEED(b) do { if (!(b)) return rt_set_error(RT_ERR_INVALID, "null builder"); } while (0)
 
-static int status_of(const std::string& msg) {
-    if (msg.find("No bounding box") != std::string::npos) return RT_ERR_NO_BBOX;
-    if (msg.find("flatten:") != std::string::npos) return RT_ERR_UNSUPPORTED;
-    return RT_ERR_INVALID;
-}
 
 extern "C" {
 
@@ -111,16 +106,19 @@ int rt_canned_scene(RtBuilder* b, const char* type, uint64_t seed, RtObj* world)
 }
 
 // ------------------------------------------------------------------ host flatten
-int rt_flat_create(const RtBuilder* b, RtObj world, RtFlat** out) {
+int rt_flat_create_ex(const RtBuilder* b, RtObj world, int flags, RtFlat** out) {
     if (!b || !out) return rt_set_error(RT_ERR_INVALID, "null argument");
     *out = nullptr;
     RtFlat* f = new RtFlat;
     std::string err;
-    if (!rt::flatten(b->b, world, f->flat, err)) { delete f; return rt_set_error(status_of(err), err); }
+    bool ok = rt::flatten(b->b, world, f->flat, err, (flags & RT_BVH_LINEAR) != 0);
+    if (ok && !f->flat.tlas_items.empty()) ok = rt::lbvh_finish_host(f->flat, err);
+    if (!ok) { delete f; return rt_set_error(rt_status_of(err), err); }
     f->view = f->flat.view();
     *out = f;
     return RT_OK;
 }
+int rt_flat_create(const RtBuilder* b, RtObj world, RtFlat** out) { return rt_flat_create_ex(b, world, 0, out); }
 const void* rt_flat_view(const RtFlat* f) { return f ? &f->view : nullptr; }
 void rt_flat_destroy(RtFlat* f) { delete f; }
 

@@ -52,6 +52,8 @@ class Flattener {
 public:
     Flattener(const Builder& b_, FlatScene& out_, std::string& err_) : b(b_), out(out_), err(err_) {}
 
+    bool defer_top = false;   // leave the top level to the linear builder: emit its items instead of nodes
+
     bool run(HittableObj world) {
         if (!b.valid_obj(world)) return fail("flatten: bad world handle");
         chains.push_back(std::vector<Op>());
@@ -81,6 +83,22 @@ public:
         }
         for (const PrimRef& p : chain_prims[0]) top.push_back(prim_item(p));
         out.blas_depth = max_blas;
+        if (defer_top && top.size() >= 2) {
+            // One item per primitive or instance: (box.min, child code), (box.max, 0).  The nodes above them are built later.
+            Box3 wb;
+            out.tlas_items.reserve(top.size() * 2);
+            for (const Item& it : top) {
+                int code = it.cls == kInstanceClass ? rt_leaf_instance(it.ref) : rt_leaf_prims(it.cls, emit_prim(it.ref), 1);
+                out.tlas_items.push_back(f4(f_down(it.box.mn[0]), f_down(it.box.mn[1]), f_down(it.box.mn[2]), i2f(code)));
+                out.tlas_items.push_back(f4(f_up(it.box.mx[0]), f_up(it.box.mx[1]), f_up(it.box.mx[2]), 0));
+                wb.grow(it.box);
+            }
+            for (int a = 0; a < 3; ++a) { out.world_box[a] = wb.mn[a]; out.world_box[3 + a] = wb.mx[a]; }
+            out.root = -1; out.tlas_depth = 0;
+            out.max_stack = out.instances.empty() ? 0 : 1 + max_blas;   // the top level's depth is added when it exists
+            relabel_breadth_first();
+            return err.empty();
+        }
         if (!top.empty()) {
             int budget = RT_STACK_DEPTH - 2 - (out.instances.empty() ? 0 : max_blas + 1);
             if (budget < 4) return fail("flatten: instance BVH too deep for the traversal stack");
@@ -459,9 +477,10 @@ RtSceneView FlatScene::view() const {
     return v;
 }
 
-bool flatten(const Builder& b, HittableObj world, FlatScene& out, std::string& err) {
+bool flatten(const Builder& b, HittableObj world, FlatScene& out, std::string& err, bool defer_top) {
     err.clear();
     Flattener f(b, out, err);
+    f.defer_top = defer_top;
     return f.run(world);
 }
 

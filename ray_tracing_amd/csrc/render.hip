@@ -78,7 +78,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev
 // LDS plan of one k_trace block (host: plan_trace).  Offsets are in 16-byte records from the start of the block's
 // dynamic LDS; an offset < 0 leaves that array in global memory.  Layout: [nodes][primitive arrays][stack].
 struct RtTracePlan {
-    int32_t n_nodes_lds;                                                  // nodes [0, n) are served from LDS
+    int32_t n_nodes_lds;                                                  // nodes [first_lds, first_lds + n) are served from LDS
+    int32_t first_lds;                                                    // 0 for a breadth-first array; a device-built tree keeps copies of its top at the end
     int32_t off_spheres, off_mspheres, off_rects, off_boxes, off_instances;
     int32_t off_stack;                                                    // first record of the stack
     int32_t stack_cap;                                                    // stack entries per lane
@@ -95,11 +96,11 @@ __device__ __forceinline__ rt_f4 lds_ld4(lds_f4* p) { rt_vf4 v = *p; rt_f4 r; r.
 // RESIDENT = the whole node array and every primitive array are in LDS: the accessors then have no global-memory path at
 // all, which matters beyond the saved branch -- with no other VMEM load in the traversal loop the compiler has no reason
 // to wait on vmcnt there, so the prefetch of the next ray batch really stays in flight.
-template <bool RESIDENT> struct TraceNodes {   // node records: the breadth-first prefix [0, n_lds) from LDS, the rest from global memory
-    const rt_f4* global; lds_f4* lds; int32_t n_lds;
+template <bool RESIDENT> struct TraceNodes {   // node records: [first, first + n_lds) (the top of the tree) from LDS, the rest from global memory
+    const rt_f4* global; lds_f4* lds; int32_t n_lds, first;
     __device__ __forceinline__ void get(int32_t n, rt_f4 q[4]) const {
-        if (RESIDENT || n < n_lds) {
-            lds_f4* p = lds + 4 * n;
+        if (RESIDENT || (uint32_t)(n - first) < (uint32_t)n_lds) {
+            lds_f4* p = lds + 4 * (RESIDENT ? n : n - first);
             q[0] = lds_ld4(p); q[1] = lds_ld4(p + 1); q[2] = lds_ld4(p + 2); q[3] = lds_ld4(p + 3);
         } else {
             const rt_f4* p = global + 4 * (size_t)n;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, 
     extern __shared__ __align__(16) unsigned char smem[];
     {   // scene -> LDS
         rt_f4* dst = reinterpret_cast<rt_f4*>(smem);
-        for (int i = threadIdx.x; i < plan.n_nodes_lds * 4; i += TB) dst[i] = ld4(sc.nodes + i);
+        for (int i = threadIdx.x; i < plan.n_nodes_lds * 4; i += TB) dst[i] = ld4(sc.nodes + 4 * (size_t)plan.first_lds + i);
         if (plan.off_spheres >= 0) for (int i = threadIdx.x; i < sc.n_spheres; i += TB) dst[plan.off_spheres + i] = ld4(sc.spheres + i);
         if (plan.off_mspheres >= 0) for (int i = threadIdx.x; i < sc.n_mspheres * 3; i += TB) dst[plan.off_mspheres + i] = ld4(sc.mspheres + i);
         if (plan.off_rects >= 0) for (int i = threadIdx.x; i < sc.n_rects * 2; i += TB) dst[plan.off_rects + i] = ld4(sc.rects + i);
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, 
     }
     __syncthreads();
     lds_f4* lds = (lds_f4*)smem;
-    TraceNodes<RESIDENT> nodes; nodes.global = sc.nodes; nodes.lds = lds; nodes.n_lds = plan.n_nodes_lds;
+    TraceNodes<RESIDENT> nodes; nodes.global = sc.nodes; nodes.lds = lds; nodes.n_lds = plan.n_nodes_lds; nodes.first = plan.first_lds;
     TracePrims<RESIDENT> prims; prims.sc = &sc; prims.lds = lds;
     prims.o_sph = plan.off_spheres; prims.o_msph = plan.off_mspheres; prims.o_rect = plan.off_rects; prims.o_box = plan.off_boxes; prims.o_inst = plan.off_instances;
     TraceStack<WIDE> stk = make_stack<WIDE>(smem, plan.off_stack, plan.stack_cap, TB);
@@ -509,6 +510,9 @@ struct RtScene {
     unsigned long long* work = nullptr;   // 16 work counters of the instrumented kernel
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> ev_trace;      // per-bounce event pairs around k_trace (RT_FLAG_TIME_TRACE)
+    const rt_f4* nodes_on_device = nullptr; // set when the top level was built on the GPU (the node array is already there)
+    double bvh_build_seconds = 0.0;        // device time of that build
+    int top_first = 0;                     // first node of the region k_trace should keep in LDS (see plan_trace)
     int trace_block = 1024;                // threads per k_trace block (1024, or 256 where a block cannot have 160 KB of LDS)
 };
 
@@ -534,10 +538,10 @@ static void launch_trace(RtScene* s, bool stats, hipStream_t st, uint32_t cap, c
 // Fills the LDS of a k_trace block of `threads` threads within `budget` bytes.  The stack always has the full depth the
 // BVH can need.  If the whole node array fits beside a stack of 16-bit entries (and node indices fit 15 bits), that form
 // is used and the room left goes to whole primitive arrays; otherwise 32-bit entries and a breadth-first node prefix.
-static void fill_plan(const RtSceneView& v, int max_stack, int threads, int budget, int refill_lanes, bool allow_narrow, RtTracePlan& pl,
-                      int& lds_bytes) {
+static void fill_plan(const RtSceneView& v, int max_stack, int threads, int budget, int refill_lanes, bool allow_narrow, int top_first,
+                      RtTracePlan& pl, int& lds_bytes) {
     const int stack_cap = std::max(1, max_stack);
-    pl.stack_cap = stack_cap; pl.refill_lanes = refill_lanes; pl.resident = 0;
+    pl.stack_cap = stack_cap; pl.refill_lanes = refill_lanes; pl.resident = 0; pl.first_lds = 0;
     pl.off_spheres = pl.off_mspheres = pl.off_rects = pl.off_boxes = pl.off_instances = -1;
     const int narrow = stack_cap * threads * 2, wide = stack_cap * threads * 4;
     int used;
@@ -560,7 +564,8 @@ static void fill_plan(const RtSceneView& v, int max_stack, int threads, int budg
         lds_bytes = used + narrow;
     } else {
         pl.wide_stack = 1;
-        pl.n_nodes_lds = std::max(0, std::min(v.n_nodes, (budget - wide) / 64));
+        pl.first_lds = top_first;
+        pl.n_nodes_lds = std::max(0, std::min(v.n_nodes - top_first, (budget - wide) / 64));
         used = pl.n_nodes_lds * 64;
         pl.off_stack = used / 16;
         lds_bytes = used + wide;
@@ -577,7 +582,7 @@ static int plan_trace(RtScene* s) {
     int blocks_per_cu = 1;
     bool planned = false;
     if (want == 1024 && s->flat.max_stack * 1024 * 4 + 64 <= 160 * 1024 - 512) {
-        fill_plan(s->view, s->flat.max_stack, 1024, 160 * 1024 - 512, refill, narrow_ok, s->plan, s->lds_bytes);
+        fill_plan(s->view, s->flat.max_stack, 1024, 160 * 1024 - 512, refill, narrow_ok, s->top_first, s->plan, s->lds_bytes);
         const void* fns[2];
         if (s->plan.resident) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, false, true>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, false, true>); }
         else if (!s->plan.wide_stack) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, false, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, false, false>); }
@@ -588,7 +593,7 @@ static int plan_trace(RtScene* s) {
         else (void)hipGetLastError();   // this device does not give one workgroup that much LDS: use the small blocks
     }
     if (!planned) {
-        fill_plan(s->view, s->flat.max_stack, 256, 40 * 1024 - 128, refill, false, s->plan, s->lds_bytes);
+        fill_plan(s->view, s->flat.max_stack, 256, 40 * 1024 - 128, refill, false, s->top_first, s->plan, s->lds_bytes);
         s->trace_block = 256; blocks_per_cu = 4;
         if (s->lds_bytes > 48 * 1024) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, 256, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
@@ -678,26 +683,85 @@ int rt_device_count(int* count) {
     return RT_OK;
 }
 
-int rt_scene_create(const RtBuilder* b, RtObj world, int device, RtScene** out) {
+static const int kTopCopies = 2048;   // nodes of a device-built tree copied to a contiguous breadth-first run (<= what LDS can hold)
+
+int rt_scene_create_ex(const RtBuilder* b, RtObj world, int device, int flags, RtScene** out) {
     if (!b || !out) return rt_set_error(RT_ERR_INVALID, "null argument");
     *out = nullptr;
-    RtFlat* flat = nullptr;
-    int rc = rt_flat_create(b, world, &flat);
-    if (rc != RT_OK) return rc;
     int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) { rt_flat_destroy(flat); return rt_set_error(RT_ERR_NO_DEVICE, "no HIP device available"); }
-    if (device < 0 || device >= n_dev) { rt_flat_destroy(flat); return rt_set_error(RT_ERR_INVALID, "device index out of range"); }
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return rt_set_error(RT_ERR_NO_DEVICE, "no HIP device available");
+    if (device < 0 || device >= n_dev) return rt_set_error(RT_ERR_INVALID, "device index out of range");
     RtScene* s = new RtScene;
     s->device = device;
-    s->flat = flat->flat;
-    rt_flat_destroy(flat);
-    rc = [&]() -> int {
+    {
+        std::string err;
+        if (!rt::flatten(b->b, world, s->flat, err, (flags & RT_BVH_LINEAR) != 0)) {
+            delete s;
+            return rt_set_error(rt_status_of(err), err);
+        }
+    }
+    int rc = [&]() -> int {
         HIP_TRY(hipSetDevice(device));
         HIP_TRY(hipDeviceGetAttribute(&s->n_cu, hipDeviceAttributeMultiprocessorCount, device));
-        const rt::FlatScene& f = s->flat;
+        rt::FlatScene& f = s->flat;
+        if (!f.tlas_items.empty()) {
+            // Deferred top level: its nodes are built on the GPU behind the bottom-level nodes, then copied back so that the
+            // host copy describes the whole tree.
+            const int n = (int)f.tlas_items.size() / 2, base = (int)f.nodes.size() / 4;
+            const rt_f4* d_items = nullptr;
+            rt_f4* d_nodes = nullptr;
+            int r;
+            if ((r = upload(s, f.tlas_items, &d_items))) return r;
+            size_t bytes = ((size_t)base + (size_t)n - 1) * 4 * sizeof(rt_f4);
+            HIP_TRY(hipMalloc((void**)&d_nodes, bytes));
+            s->allocs.push_back(d_nodes); s->device_bytes += bytes;
+            if (base > 0) HIP_TRY(hipMemcpy(d_nodes, f.nodes.data(), (size_t)base * 4 * sizeof(rt_f4), hipMemcpyHostToDevice));
+            rt::LbvhFrameHost fr = rt::lbvh_frame(f);
+            int depth = 0; std::string err;
+            if (!rt::lbvh_build_device(fr.lo, fr.inv_ext, d_items, n, d_nodes + 4 * (size_t)base, base, &depth, &s->bvh_build_seconds, err))
+                return rt_set_error(RT_ERR_HIP, err);
+            f.nodes.resize(((size_t)base + (size_t)n - 1) * 4);
+            HIP_TRY(hipMemcpy(f.nodes.data(), d_nodes, bytes, hipMemcpyDeviceToHost));
+            f.root = base; f.tlas_depth = depth; f.max_stack += depth;
+            if (f.max_stack > RT_STACK_DEPTH) return rt_set_error(RT_ERR_UNSUPPORTED, "linear BVH deeper than the traversal stack");
+            // The radix tree's nodes are numbered by sorted position, not by level, so the top of the tree is scattered over
+            // the array.  k_trace keeps a contiguous run of nodes in LDS: copies of the top levels, in breadth-first order and
+            // with their links redirected to each other, are appended and become that run (and the root).
+            const int total = base + n - 1;
+            if (total > kTopCopies) {
+                std::vector<int> order(1, f.root);
+                for (size_t head = 0; head < order.size() && (int)order.size() < kTopCopies; ++head)
+                    for (int c = 0; c < 2 && (int)order.size() < kTopCopies; ++c) {
+                        int32_t child; std::memcpy(&child, c == 0 ? &f.nodes[(size_t)order[head] * 4 + 3].x : &f.nodes[(size_t)order[head] * 4 + 3].y, 4);
+                        if (child >= 0) order.push_back(child);
+                    }
+                std::vector<rt_f4> top(order.size() * 4);
+                // order[k] gets copy index total + k; a child that is itself copied is order[j] for the j at which it was pushed
+                size_t next = 1;
+                for (size_t k = 0; k < order.size(); ++k) {
+                    for (int q = 0; q < 4; ++q) top[k * 4 + q] = f.nodes[(size_t)order[k] * 4 + q];
+                    for (int c = 0; c < 2; ++c) {
+                        float& w = c == 0 ? top[k * 4 + 3].x : top[k * 4 + 3].y;
+                        int32_t child; std::memcpy(&child, &w, 4);
+                        if (child >= 0 && next < order.size() && order[next] == child) { int32_t nc = total + (int)next; std::memcpy(&w, &nc, 4); ++next; }
+                    }
+                }
+                rt_f4* d_all = nullptr;
+                size_t all_bytes = ((size_t)total + order.size()) * 4 * sizeof(rt_f4);
+                HIP_TRY(hipMalloc((void**)&d_all, all_bytes));
+                s->allocs.push_back(d_all); s->device_bytes += all_bytes;
+                HIP_TRY(hipMemcpy(d_all, d_nodes, bytes, hipMemcpyDeviceToDevice));
+                HIP_TRY(hipMemcpy(d_all + 4 * (size_t)total, top.data(), top.size() * sizeof(rt_f4), hipMemcpyHostToDevice));
+                f.nodes.insert(f.nodes.end(), top.begin(), top.end());
+                f.root = total; s->top_first = total;
+                d_nodes = d_all;
+            }
+            s->nodes_on_device = d_nodes;
+        }
         RtSceneView v = f.view();
         int r;
-        if ((r = upload(s, f.nodes, &v.nodes))) return r;
+        if (s->nodes_on_device) v.nodes = s->nodes_on_device;
+        else if ((r = upload(s, f.nodes, &v.nodes))) return r;
         if ((r = upload(s, f.spheres, &v.spheres))) return r;
         if ((r = upload(s, f.sphere_meta, &v.sphere_meta))) return r;
         if ((r = upload(s, f.mspheres, &v.mspheres))) return r;
@@ -720,6 +784,7 @@ int rt_scene_create(const RtBuilder* b, RtObj world, int device, RtScene** out) 
     *out = s;
     return RT_OK;
 }
+int rt_scene_create(const RtBuilder* b, RtObj world, int device, RtScene** out) { return rt_scene_create_ex(b, world, device, 0, out); }
 
 void rt_scene_destroy(RtScene* s) {
     if (!s) return;
@@ -740,11 +805,11 @@ static void fill_info(const rt::FlatScene& f, RtSceneInfo* o) {
     o->n_instances = v.n_instances; o->n_media = v.n_media; o->n_materials = v.n_materials; o->n_textures = v.n_textures; o->n_perlin = v.n_perlin;
     o->tlas_depth = f.tlas_depth; o->blas_depth = f.blas_depth; o->max_stack = f.max_stack; o->n_objects = f.n_ids; o->device = -1;
     for (int i = 0; i < 6; ++i) o->world_box[i] = f.world_box[i];
-    o->device_bytes = 0;
+    o->device_bytes = 0; o->bvh_build_seconds = 0.0;
 }
 int rt_scene_info(const RtScene* s, RtSceneInfo* out) {
     if (!s || !out) return rt_set_error(RT_ERR_INVALID, "null argument");
-    fill_info(s->flat, out); out->device = s->device; out->device_bytes = s->device_bytes;
+    fill_info(s->flat, out); out->device = s->device; out->device_bytes = s->device_bytes; out->bvh_build_seconds = s->bvh_build_seconds;
     return RT_OK;
 }
 int rt_flat_info(const RtFlat* f, RtSceneInfo* out) {

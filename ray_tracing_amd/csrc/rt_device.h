@@ -14,7 +14,7 @@
 #include <string.h>
 #include "rt_types.h"
 
-#if defined(__HIPCC__)
+#if defined(__HIP__)   /* compiled as HIP (a .cpp built by hipcc is plain C++) */
 #define RT_HD __host__ __device__ __forceinline__
 #define RT_HDM __host__ __device__ __forceinline__   /* member functions */
 #else

@@ -137,12 +137,20 @@ struct FlatScene {
     std::vector<rt_f4> nodes, spheres, mspheres, rects, boxes, instances, ops, media, materials, textures, perlin_vec;
     std::vector<rt_i2> sphere_meta, msphere_meta, rect_meta;
     std::vector<uint8_t> perlin_perm;
+    std::vector<rt_f4> tlas_items;   // deferred top level (flatten(..., defer_top)): 2 records per item, see lbvh.h
     int root = -1, max_stack = 0, tlas_depth = 0, blas_depth = 0, n_ids = 0;
     double world_box[6] = {0, 0, 0, 0, 0, 0};
     RtSceneView view() const;  // host pointers
 };
 // Flattens the tree under `world` (what main.rs:531 wraps in BvhNode::new).  Returns false and
 // sets err for trees the flat form cannot express (e.g. an object without a bounding box).
-bool flatten(const Builder& b, HittableObj world, FlatScene& out, std::string& err);
+// defer_top: the top-level BVH is not built; out.tlas_items holds its leaves (unless there are fewer than two, in which
+// case the normal builder runs) and out.root stays -1 until lbvh_finish_host or the device builder appends the nodes.
+bool flatten(const Builder& b, HittableObj world, FlatScene& out, std::string& err, bool defer_top = false);
+// Builds the deferred top level as a linear BVH on the host, with the per-element steps of lbvh.h in plain loops.
+bool lbvh_finish_host(FlatScene& f, std::string& err);
+// Scene box of the deferred items -> Morton frame.
+struct LbvhFrameHost { float lo[3], inv_ext[3]; };
+LbvhFrameHost lbvh_frame(const FlatScene& f);
 
 }  // namespace rt

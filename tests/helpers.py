@@ -214,9 +214,9 @@ def oracle_render(ob, ocam, width, height, spp, max_depth, seed, sample_offset=0
 class FlatScene:
     """Host-only flatten of a ray_tracing_amd.Builder tree (no GPU): the RtSceneView the kernels would read."""
 
-    def __init__(self, builder, world):
+    def __init__(self, builder, world, flags=0):
         self.h = _P()
-        rc = rt.lib().rt_flat_create(builder._h, world, C.byref(self.h))
+        rc = rt.lib().rt_flat_create_ex(builder._h, world, flags, C.byref(self.h))
         if rc != 0:
             raise rt.RtError(rc, rt.lib().rt_last_error().decode())
         self.view = rt.lib().rt_flat_view(self.h)

@@ -156,3 +156,42 @@ def test_nested_transforms_and_unsupported_trees():
     with pytest.raises(rt.RtError) as e:             # empty boundary has no bounding box (bvh.rs:140)
         b.flatten_info(b.list([b.constant_medium_from_color(b.list([]), 0.1, (1, 1, 1))]))
     assert e.value.code == -5
+
+
+@pytest.mark.parametrize("name", ["random.yml", "cornell.yml", "final_scene.yml", "showcase.yml"])
+def test_linear_bvh_invariants(name):
+    """RT_BVH_LINEAR: the top level built as a radix tree over Morton-sorted items (here with the host loops that mirror the
+    GPU kernels).  Same invariants as the SAH tree: every primitive reachable once, child boxes contain their content."""
+    cfg, cam, b, world, ob = scene_pair(name)
+    flat = FlatScene(b, world, rt.RT_BVH_LINEAR)
+    a = arrays(flat)
+    info = flat.info()
+    ref = FlatScene(b, world).info()
+    seen, stats = set(), dict(depth=0, inst=[])
+    walk(a, a["root"], seen, 0, stats, False)
+    n_bound = {0: 0, 1: 0, 2: 0, 3: 0}
+    for m in a["media"]:
+        iv = m.view(np.int32)
+        n_bound[0] += iv[10]; n_bound[1] += iv[12]; n_bound[2] += iv[14]; n_bound[3] += iv[17]
+    assert len([s for s in seen if s[0] == 0]) == info.n_spheres - n_bound[0] == ref.n_spheres - n_bound[0]
+    assert len([s for s in seen if s[0] == 1]) == info.n_moving_spheres - n_bound[1]
+    assert len([s for s in seen if s[0] == 2]) == info.n_rects - n_bound[2]
+    assert len([s for s in seen if s[0] == 3]) == info.n_boxes - n_bound[3]
+    assert len(stats["inst"]) == info.n_instances - sum(1 for m in a["media"] if m.view(np.int32)[8] >= 0)
+    assert stats["depth"] == info.tlas_depth and info.max_stack <= 32
+    assert np.allclose(list(info.world_box), list(ref.world_box), atol=1e-3)
+
+
+def test_linear_bvh_traversal_matches_oracle():
+    """Closest hits do not depend on the tree: the emulated traversal of the linear BVH agrees with the oracle like the SAH tree does."""
+    from helpers import OracleCamera, RENDER_SEED, emul_trace_primary, oracle_trace_primary, primary_agreement
+    for name in ["random.yml", "final_scene.yml"]:
+        cfg, cam, b, world, ob = scene_pair(name)
+        W, H = 96, int(round(96 / cfg.aspect_ratio))
+        p = rt.render_params(W, H, 1, 50, RENDER_SEED)
+        lin = emul_trace_primary(FlatScene(b, world, rt.RT_BVH_LINEAR), cam, p, 0)
+        sah = emul_trace_primary(FlatScene(b, world), cam, p, 0)
+        o = oracle_trace_primary(ob, OracleCamera(cam), W, H, 0, RENDER_SEED)
+        agree, rel = primary_agreement(lin, o)
+        assert agree >= 0.999 and rel <= 1e-4, (name, agree, rel)
+        assert np.array_equal(lin["id"], sah["id"]) and np.array_equal(lin["t"], sah["t"])

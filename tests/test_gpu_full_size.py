@@ -174,3 +174,40 @@ def test_cli_checkpoint_and_resume(gpu_required, tmp_path):
     scene.close()
     want = rt.tonemap_u8(whole, 12)
     assert np.abs(img.astype(int) - want.astype(int)).max() <= 1                    # fp32 summation order only
+
+
+@pytest.mark.parametrize("name", ["final_scene.yml", "random.yml", "showcase.yml"])
+def test_device_built_linear_bvh(gpu_required, name):
+    """RT_BVH_LINEAR: the top level is built on the GPU; it must be the tree the host mirror of the same steps builds, and it
+    must give the same closest hits and the same image as the SAH tree (hits do not depend on the tree)."""
+    cfg, cam = config_camera(name)
+    path = os.path.join(CONFIGS, name)
+    b = rt.Builder()
+    world = b.scene_from_config(path, SCENE_SEED)
+    host = b.flatten_info(world, rt.RT_BVH_LINEAR)
+    lin = rt.Scene(b, world, 0, rt.RT_BVH_LINEAR)
+    sah = rt.Scene(b, world, 0)
+    li, si = lin.info(), sah.info()
+    assert (li.n_nodes, li.tlas_depth, li.max_stack) == (host.n_nodes, host.tlas_depth, host.max_stack)
+    assert li.bvh_build_seconds > 0 and si.bvh_build_seconds == 0
+    W, H = 200, int(round(200 / cfg.aspect_ratio))
+    p = rt.render_params(W, H, 4, cfg.max_depth, RENDER_SEED)
+    a, c = lin.trace_primary(cam, p, 0), sah.trace_primary(cam, p, 0)
+    assert np.array_equal(a["id"], c["id"]) and np.array_equal(a["t"], c["t"])
+    img_l, _, st_l = lin.render(cam, p)
+    img_s, _, st_s = sah.render(cam, p)
+    assert st_l.rays == st_s.rays and np.array_equal(img_l, img_s)
+    lin.close(); sah.close()
+
+
+def test_device_built_linear_bvh_one_million_spheres(gpu_required):
+    b = rt.Builder()
+    w = b.canned_scene("Synthetic:1000000", SCENE_SEED)
+    scene = rt.Scene(b, w, 0, rt.RT_BVH_LINEAR)
+    info = scene.info()
+    assert info.n_spheres == 1000001 and info.n_nodes == 1000000 + 2048 and info.max_stack <= 32   # + copies of the top levels
+    assert 0 < info.bvh_build_seconds < 0.5
+    cam = rt.make_camera((0, 260, 1500), (0, 60, 0), (0, 1, 0), 40.0, 16 / 9, 0.1, 10.0)
+    img, _, st = scene.render(cam, rt.render_params(480, 270, 2, 50, RENDER_SEED, background=(0.7, 0.8, 1.0)))
+    assert np.isfinite(img).all() and st.rays > 480 * 270 * 2
+    scene.close()
