@@ -2,7 +2,7 @@
 //
 // Wavefront organisation of one pass over P = W*H*spp_chunk paths (replaces src/main.rs:567-599):
 //   k_raygen      : Philox camera rays (pixel jitter, lens, shutter time) -> ray queue 0
-//   per bounce    : k_trace  closest surface hit of every queued ray (two-level BVH, top levels in LDS, persistent
+//   per bounce    : k_trace  closest surface hit of every queued ray (two-level BVH, the scene or its top levels in LDS, persistent
 //                            waves that refill finished lanes with new rays) -> hit record per ray
 //                   k_shade  media, hit record, emission, scatter; append of the scattered ray to the other queue
 //                            through a wave-aggregated atomic (one atomic per 64-lane wave, ranks from ballot +

@@ -1,5 +1,5 @@
 // rt_device.h -- the fp32 path-tracing arithmetic of the gfx950 kernels, written as inline
-// functions so that kernels.hip can arrange them into wavefront stages.  The functions restate,
+// functions so that render.hip can arrange them into wavefront stages.  The functions restate,
 // in fp32 and without recursion or virtual dispatch, the per-ray work of the reference:
 //   camera ray          cameras.rs:82-98        closest hit   bvh.rs:159-187, objects.rs:67-78
 //   sphere              objects.rs:205-239      moving sphere objects.rs:292-326
