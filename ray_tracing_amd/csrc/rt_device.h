@@ -248,13 +248,18 @@ RT_HD v3 rt_msphere_center(rt_f4 m0, rt_f4 m1, rt_f4 m2, float time) {  // objec
 // Slab test (bvh.rs:46-61) against the interval [tmin, tmax]; returns the entry t or +inf.
 // fminf/fmaxf drop NaNs (0 * inf when a direction component is 0 and the origin lies on the slab
 // plane), which keeps the test conservative.
-RT_HD float rt_slab(float lx, float ly, float lz, float hx, float hy, float hz, v3 o, v3 inv, float tmin, float tmax) {
+// rt_slab_hit: whether the box is hit, and the entry t in `tn` (meaningful only then).
+RT_HD bool rt_slab_hit(float lx, float ly, float lz, float hx, float hy, float hz, v3 o, v3 inv, float tmin, float tmax, float& tn) {
     float t0x = (lx - o.x) * inv.x, t1x = (hx - o.x) * inv.x;
     float t0y = (ly - o.y) * inv.y, t1y = (hy - o.y) * inv.y;
     float t0z = (lz - o.z) * inv.z, t1z = (hz - o.z) * inv.z;
-    float tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
+    tn = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
     float tf = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), tmax));
-    return tn <= tf ? tn : rt_inf();
+    return tn <= tf;
+}
+RT_HD float rt_slab(float lx, float ly, float lz, float hx, float hy, float hz, v3 o, v3 inv, float tmin, float tmax) {
+    float tn;
+    return rt_slab_hit(lx, ly, lz, hx, hy, hz, o, inv, tmin, tmax, tn) ? tn : rt_inf();
 }
 
 // ------------------------------------------------------------------ instances (transrot.rs)
@@ -327,10 +332,10 @@ RT_HD void rt_node_step(const Nodes& nodes, RtTrav& tv, float tmin, const RtHit&
     const int32_t node = tv.cur;
     nodes.get(node, q);
     if (STATS) wc->nodes++;
-    float tl = rt_slab(q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, tv.o, tv.inv, tmin, hit.t);
-    float tr = rt_slab(q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, tv.o, tv.inv, tmin, hit.t);
+    float tl, tr;
+    bool hl = rt_slab_hit(q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, tv.o, tv.inv, tmin, hit.t, tl);
+    bool hr = rt_slab_hit(q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, tv.o, tv.inv, tmin, hit.t, tr);
     int32_t cl = f2i(q[3].x), cr = f2i(q[3].y);
-    bool hl = tl < rt_inf(), hr = tr < rt_inf();
     if (hl && hr) {
         bool left_first = tl <= tr;
         if (tv.sp < stk.cap()) stk.put(tv.sp++, node, left_first ? 1 : 0, left_first ? cr : cl);
