@@ -184,7 +184,8 @@ def main():
                          "note": "bytes_per_ray = 32 B ray record in + 16 B hit record out + 64 B per visited BVH node + the record of every "
                                  "primitive tested; the node records come from the LDS copy of the <1 MB scene, so frac can exceed 1 on the "
                                  "HBM line -- hbm_only counts just the ray and hit records, the bytes that must cross HBM.  The kernel is bound "
-                                 "by dependent-instruction latency of divergent traversal, not by HBM or VALU throughput"},
+                                 "by VALU instruction issue of divergent traversal at partial lane occupancy (the fp32 FLOP rate of "
+                                 "roofline_valu counts live lanes only), not by HBM"},
             "roofline_valu": {"kernel": "k_trace", "bound": "valu_fp32", "achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": tfl / VALU_PEAK_TFLOPS, "flops_per_ray": tr_flops},
             "bounce_total": {"kernels": "k_trace + k_shade", "ms": main_run["kernel_ms"], "launch_pairs": main_run["launches"],
