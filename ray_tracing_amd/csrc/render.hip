@@ -12,7 +12,8 @@
 // A ray queue is RT_SHARDS regions of `cap` slots, each with its own counter: a single append counter saturates
 // at ~88 M returning atomics/s on this GPU (= 5.6 Grays/s at one atomic per 64-lane wave), 16 counters do not.
 // Block (x, y) of the bounce grid reads region y and appends to region (x + y) % RT_SHARDS; with gridDim.x a
-// multiple of RT_SHARDS no region can receive more than n/RT_SHARDS + 256 * (RT_SHARDS + 1) rays.
+// multiple of RT_SHARDS no region can receive more than n/RT_SHARDS + B * (RT_SHARDS + 1) rays (B = rays per block
+// and grid-stride step: 256 for k_shade, 1024 for k_shade_lds).
 // Queue sizes live in device memory (counts[b][s] = rays of region s entering bounce b), so a pass runs
 // without a host round trip; the counts double as the ray-segment statistics.
 #include <hip/hip_runtime.h>
@@ -274,9 +275,97 @@ struct ShadeMedia {   // medium records: the first RT_SHADE_MEDIA_LDS media from
     }
 };
 
-// Stage 2 of a bounce: media (mediums.rs:39-87), hit record, emission and scatter (lib.rs:64-71) for every ray of the
-// input queue, and the append of the scattered ray to the output queue through one wave-aggregated atomic
-// (ranks from ballot + mbcnt).  STATS = true also counts shades per material kind into `work` (16 x u64).
+// ---- k_shade / k_shade_lds: stage 2 of a bounce
+// Media (mediums.rs:39-87), hit record, emission and scatter (lib.rs:64-71) of one ray: a = (origin, time), b = (direction,
+// source primitive), c = (throughput, path id), h = (t, hit code, instance).  Light that reaches the path goes to its
+// contribution slot; out.alive = the path continues with the ray out.na / nb / nc.  out.postponed = the hit needs a costly
+// texture and `may_postpone` was set: nothing has been written for the ray then.
+// Tab: see RtGlobalTables; MediaSrc: see rt_media_hits.  STATS = true also counts shades per material kind into `work`.
+struct ShadeOut { bool alive, postponed; rt_f4 na, nb, nc; };
+template <bool STATS, class Tab, class MediaSrc>
+__device__ __forceinline__ void shade_ray(const RtSceneView& sc, const Tab& tab, const MediaSrc& msrc, const RtFrameDev& fr, int bounce,
+                                          rt_f4 a, rt_f4 b, rt_f4 c, rt_f4 h, bool may_postpone, rt_f4* contrib,
+                                          unsigned long long* work, ShadeOut& out) {
+    v3 o = mk3(a.x, a.y, a.z), d = mk3(b.x, b.y, b.z), beta = mk3(c.x, c.y, c.z);
+    float time = a.w;
+    uint32_t pid = (uint32_t)f2i(c.w);
+    uint32_t pixel, sample;
+    rt_split_path(fr, pid, pixel, sample);
+    sample += (uint32_t)fr.sample_base;
+    uint32_t rnd[4];
+    rt_philox(pixel, sample, (uint32_t)bounce, 0u, fr.key0, fr.key1, rnd);
+
+    RtHit hit; hit.t = h.x; hit.code = (uint32_t)f2i(h.y); hit.inst = f2i(h.z);
+    if (sc.n_media > 0) rt_media_hits(sc, msrc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, rnd, hit);
+
+    v3 add = mk3(0, 0, 0);
+    if (hit.code == RT_HIT_NONE) {
+        if (STATS) { atomicAdd(work + 5, (unsigned long long)sc.n_media); atomicAdd(work + 6, 1ull); }
+        add = beta * mk3(fr.background[0], fr.background[1], fr.background[2]);  // lib.rs:76
+    } else {
+        RtSurface sf;
+        rt_surface(tab, o, d, time, hit, false, sf);
+        rt_f4 a0, a1;
+        tab.material(sf.mat, a0, a1);
+        out.postponed = may_postpone && f2i(a1.w) != 0;
+        if (!out.postponed) {
+            v3 atten, dir, emitted;
+            bool scattered = rt_scatter(tab, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), atten, dir, emitted);
+            if (STATS) {
+                atomicAdd(work + 5, (unsigned long long)sc.n_media);
+                int mtype = f2i(a0.x), mtex = f2i(a0.y);
+                atomicAdd(work + 8 + mtype, 1ull);                                     // shades per material kind
+                if (mtex >= 0 && mtype != RT_MAT_METAL && mtype != RT_MAT_DIELECTRIC) { // texture kind behind the material
+                    int tt = f2i(ld4(sc.textures + 2 * (size_t)mtex).x);
+                    if (tt == RT_TEX_NOISE) atomicAdd(work + 13, 1ull); else if (tt == RT_TEX_CHECKER) atomicAdd(work + 14, 1ull);
+                }
+            }
+            add = beta * emitted;                                                      // lib.rs:64,66
+            if (scattered && bounce < fr.max_depth) {                                 // lib.rs:58-60
+                beta = beta * atten;
+                out.alive = true;
+                out.na.x = sf.p.x; out.na.y = sf.p.y; out.na.z = sf.p.z; out.na.w = time;
+                out.nb.x = dir.x; out.nb.y = dir.y; out.nb.z = dir.z;
+                out.nb.w = i2f(RT_HIT_KIND(hit.code) == RT_KIND_MEDIUM ? (int)RT_HIT_NONE : (int)hit.code);
+                out.nc.x = beta.x; out.nc.y = beta.y; out.nc.z = beta.z; out.nc.w = c.w;
+            }
+        }
+    }
+    if (add.x != 0.0f || add.y != 0.0f || add.z != 0.0f) {
+        // Light reaches a path where it ends (an emitter does not scatter, a miss has no next segment), so the
+        // path's slot, zeroed before the pass, is written exactly once; only a surface that both emits and
+        // scatters would have to add to an earlier value.
+        float4* cp = reinterpret_cast<float4*>(contrib + pid);
+        float4 cv = make_float4(add.x, add.y, add.z, 0.0f);
+        if (out.alive) { float4 old = *cp; cv.x += old.x; cv.y += old.y; cv.z += old.z; }
+        *cp = cv;
+    }
+}
+__device__ __forceinline__ void shade_out_clear(ShadeOut& out) {
+    out.alive = false; out.postponed = false;
+    out.na.x = out.na.y = out.na.z = out.na.w = out.nb.x = out.nb.y = out.nb.z = out.nb.w = out.nc.x = out.nc.y = out.nc.z = out.nc.w = 0.0f;
+}
+// Append of the scattered rays of one wave to the output queue: one atomic per wave, slot = base + rank among the live
+// lanes (ballot + mbcnt).  Wave-uniform control flow only.  Returns whether any lane appended; the wave has then waited
+// for every vector memory operation it had issued before this call (the atomic's result is the last of them).
+__device__ __forceinline__ bool shade_append(const ShadeOut& out, uint32_t* n_out_ptr, uint32_t cap, rt_f4* oa, rt_f4* ob, rt_f4* oc) {
+    unsigned long long mask = __ballot(out.alive);
+    if (!mask) return false;
+    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    uint32_t slot0 = 0;
+    if (out.alive && rank == 0) slot0 = atomicAdd(n_out_ptr, (uint32_t)__popcll(mask));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    slot0 = __shfl(slot0, __ffsll((long long)mask) - 1);
+    if (out.alive && slot0 + rank < cap) {  // the capacity bound holds by construction; the test only guards memory
+        uint32_t slot = slot0 + rank;
+        *reinterpret_cast<float4*>(oa + slot) = make_float4(out.na.x, out.na.y, out.na.z, out.na.w);
+        *reinterpret_cast<float4*>(ob + slot) = make_float4(out.nb.x, out.nb.y, out.nb.z, out.nb.w);
+        *reinterpret_cast<float4*>(oc + slot) = make_float4(out.nc.x, out.nc.y, out.nc.z, out.nc.w);
+    }
+    return true;
+}
+
+// One ray per lane, grid-stride, tables from global memory (any scene).  The input queue region is blockIdx.y.
 template <bool STATS>
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev fr, int bounce, uint32_t cap, const uint32_t* counts_in,
                                                     uint32_t* counts_out, const rt_f4* ia, const rt_f4* ib, const rt_f4* ic,
@@ -289,120 +378,18 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev f
     for (int i = threadIdx.x; i < min(sc.n_media, RT_SHADE_MEDIA_LDS) * RT_MEDIUM_F4; i += RT_BLOCK) s_media[i] = ld4(sc.media + i);
     __syncthreads();
     ShadeMedia msrc; msrc.global = sc.media; msrc.lds = (lds_f4*)s_media;
+    RtGlobalTables tab; tab.sc = &sc;
     const uint32_t out_shard = (blockIdx.x + blockIdx.y) % RT_SHARDS;
     uint32_t* n_out_ptr = counts_out + out_shard * RT_COUNT_STRIDE;
     ia += (size_t)blockIdx.y * cap; ib += (size_t)blockIdx.y * cap; ic += (size_t)blockIdx.y * cap; hits += (size_t)blockIdx.y * cap;
     oa += (size_t)out_shard * cap; ob += (size_t)out_shard * cap; oc += (size_t)out_shard * cap;
-#ifdef RT_SHADE_CLOCK   /* variant builds only: wave clocks per section of the loop body, summed into work[20..27] */
-    unsigned long long clk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_readcyclecounter();
-#define RT_TICK(k_) do { unsigned long long t_ = __builtin_readcyclecounter(); clk[k_] += t_ - t_prev; t_prev = t_; } while (0)
-#else
-#define RT_TICK(k_) do { } while (0)
-#endif
 
-    // One ray per lane.  Returns true when the hit was postponed (costly texture, `may_postpone`): nothing has been
-    // written for that ray then.  Called from wave-uniform control flow only (the append votes over the wave).
+    // Returns true when the hit was postponed.  Called from wave-uniform control flow only (the append votes over the wave).
     auto shade = [&](uint32_t i, bool valid, bool may_postpone) -> bool {
-        bool alive = false, postponed = false;
-        rt_f4 na, nb, nc;
-        na.x = na.y = na.z = na.w = nb.x = nb.y = nb.z = nb.w = nc.x = nc.y = nc.z = nc.w = 0.0f;
-        if (valid) {
-            rt_f4 a = ld4(ia + i), b = ld4(ib + i), c = ld4(ic + i), h = ld4(hits + i);
-            v3 o = mk3(a.x, a.y, a.z), d = mk3(b.x, b.y, b.z), beta = mk3(c.x, c.y, c.z);
-            float time = a.w;
-            uint32_t pid = (uint32_t)f2i(c.w);
-            uint32_t pixel, sample;
-            rt_split_path(fr, pid, pixel, sample);
-            sample += (uint32_t)fr.sample_base;
-            uint32_t rnd[4];
-            rt_philox(pixel, sample, (uint32_t)bounce, 0u, fr.key0, fr.key1, rnd);
-#ifdef RT_SHADE_CLOCK
-            asm volatile("" ::"v"(a.x), "v"(b.x), "v"(c.x), "v"(h.x));   // the loads have landed before the clock is read
-#endif
-            RT_TICK(0);
-
-            RtHit hit; hit.t = h.x; hit.code = (uint32_t)f2i(h.y); hit.inst = f2i(h.z);
-#ifdef RT_MEDIA_TWICE   /* timing experiment: the media test run twice with the same result */
-            if (sc.n_media > 0) {
-                RtHit h2 = hit;
-                rt_media_hits(sc, msrc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, rnd, h2);
-                asm volatile("" : "+v"(o.x), "+v"(d.x), "+v"(h2.t));
-                if (h2.t < 0.0f) hit.t = h2.t;   // never true; keeps the first call alive
-            }
-#endif
-            if (sc.n_media > 0) rt_media_hits(sc, msrc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, rnd, hit);
-            RT_TICK(1);
-
-            v3 add = mk3(0, 0, 0);
-            if (hit.code == RT_HIT_NONE) {
-                if (STATS) { atomicAdd(work + 5, (unsigned long long)sc.n_media); atomicAdd(work + 6, 1ull); }
-                add = beta * mk3(fr.background[0], fr.background[1], fr.background[2]);  // lib.rs:76
-            } else {
-                RtSurface sf;
-                rt_surface(sc, o, d, time, hit, false, sf);
-                RT_TICK(2);
-                rt_f4 a0 = ld4(sc.materials + 2 * (size_t)sf.mat), a1 = ld4(sc.materials + 2 * (size_t)sf.mat + 1);
-                postponed = may_postpone && f2i(a1.w) != 0;
-                if (!postponed) {
-                    v3 atten, dir, emitted;
-#ifdef RT_SCATTER_TWICE   /* timing experiment */
-                    {
-                        RtSurface sf2; v3 at2, dir2, em2;
-                        rt_surface(sc, o, d, time, hit, false, sf2);
-                        bool s2 = rt_scatter(sc, sf2, d, rt_u24(rnd[0]), rt_u24(rnd[1]), at2, dir2, em2);
-                        asm volatile("" : "+v"(o.x), "+v"(d.x), "+v"(at2.x), "+v"(dir2.x), "+v"(em2.x));
-                        if (s2 && at2.x < -1.0f) beta.x = dir2.x + em2.x;   // never true
-                    }
-#endif
-                    bool scattered = rt_scatter(sc, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), atten, dir, emitted);
-                    RT_TICK(3);
-                    if (STATS) {
-                        atomicAdd(work + 5, (unsigned long long)sc.n_media);
-                        int mtype = f2i(a0.x), mtex = f2i(a0.y);
-                        atomicAdd(work + 8 + mtype, 1ull);                                     // shades per material kind
-                        if (mtex >= 0 && mtype != RT_MAT_METAL && mtype != RT_MAT_DIELECTRIC) { // texture kind behind the material
-                            int tt = f2i(ld4(sc.textures + 2 * (size_t)mtex).x);
-                            if (tt == RT_TEX_NOISE) atomicAdd(work + 13, 1ull); else if (tt == RT_TEX_CHECKER) atomicAdd(work + 14, 1ull);
-                        }
-                    }
-                    add = beta * emitted;                                                      // lib.rs:64,66
-                    if (scattered && bounce < fr.max_depth) {                                 // lib.rs:58-60
-                        beta = beta * atten;
-                        alive = true;
-                        na.x = sf.p.x; na.y = sf.p.y; na.z = sf.p.z; na.w = time;
-                        nb.x = dir.x; nb.y = dir.y; nb.z = dir.z;
-                        nb.w = i2f(RT_HIT_KIND(hit.code) == RT_KIND_MEDIUM ? (int)RT_HIT_NONE : (int)hit.code);
-                        nc.x = beta.x; nc.y = beta.y; nc.z = beta.z; nc.w = c.w;
-                    }
-                }
-            }
-            if (add.x != 0.0f || add.y != 0.0f || add.z != 0.0f) {
-                // Light reaches a path where it ends (an emitter does not scatter, a miss has no next segment), so the
-                // path's slot, zeroed before the pass, is written exactly once; only a surface that both emits and
-                // scatters would have to add to an earlier value.
-                float4* cp = reinterpret_cast<float4*>(contrib + pid);
-                float4 cv = make_float4(add.x, add.y, add.z, 0.0f);
-                if (alive) { float4 old = *cp; cv.x += old.x; cv.y += old.y; cv.z += old.z; }
-                *cp = cv;
-            }
-            RT_TICK(4);
-        }
-        // wave-aggregated append: one atomic per wave, slot = base + rank among the live lanes
-        unsigned long long mask = __ballot(alive);
-        if (mask) {
-            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-            uint32_t slot0 = 0;
-            if (alive && rank == 0) slot0 = atomicAdd(n_out_ptr, (uint32_t)__popcll(mask));
-            slot0 = __shfl(slot0, __ffsll((long long)mask) - 1);
-            if (alive && slot0 + rank < cap) {  // the capacity bound holds by construction; the test only guards memory
-                uint32_t slot = slot0 + rank;
-                *reinterpret_cast<float4*>(oa + slot) = make_float4(na.x, na.y, na.z, na.w);
-                *reinterpret_cast<float4*>(ob + slot) = make_float4(nb.x, nb.y, nb.z, nb.w);
-                *reinterpret_cast<float4*>(oc + slot) = make_float4(nc.x, nc.y, nc.z, nc.w);
-            }
-        }
-        RT_TICK(5);
-        return postponed;
+        ShadeOut out; shade_out_clear(out);
+        if (valid) shade_ray<STATS>(sc, tab, msrc, fr, bounce, ld4(ia + i), ld4(ib + i), ld4(ic + i), ld4(hits + i), may_postpone, contrib, work, out);
+        shade_append(out, n_out_ptr, cap, oa, ob, oc);
+        return out.postponed;
     };
 
     // Hits on costly textures (Perlin turbulence: ~1300 instructions) are rare per wave but present in every other wave;
@@ -434,10 +421,134 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev f
         uint32_t j = lane < n_later ? later[lane] : 0u;
         shade(j, lane < n_later, false);
     }
-#ifdef RT_SHADE_CLOCK
-    if ((threadIdx.x & 63) == 0) for (int k = 0; k < 8; ++k) if (clk[k]) atomicAdd(work + 20 + k, clk[k]);
-#endif
-#undef RT_TICK
+}
+
+// LDS plan of one k_shade_lds block (host: plan_shade): offsets in 16-byte records from the start of the block's dynamic
+// LDS.  Layout: [per wave: 4 x 64 staged ray records][per wave: 128 postponed indices][every table shading reads].
+struct RtShadePlan {
+    int32_t off_spheres, off_sphere_meta, off_mspheres, off_msphere_meta, off_rects, off_rect_meta, off_boxes, off_instances, off_ops,
+            off_materials, off_textures, off_media, off_perlin_vec, off_perlin_perm, off_stage, off_later;
+};
+typedef int __attribute__((ext_vector_type(2))) rt_vi2;
+typedef __attribute__((address_space(3))) const rt_vi2 lds_i2;
+typedef __attribute__((address_space(3))) const unsigned char lds_u8;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+struct ShadeTables {   // every table from the block's LDS copy
+    lds_f4* lds; RtShadePlan pl;
+    __device__ __forceinline__ void pair(int32_t off, uint32_t i, rt_f4& r0, rt_f4& r1) const { lds_f4* m = lds + off + 2 * i; r0 = lds_ld4(m); r1 = lds_ld4(m + 1); }
+    __device__ __forceinline__ rt_i2 meta(int32_t off, uint32_t i) const { rt_vi2 v = ((lds_i2*)(lds + off))[i]; rt_i2 r; r.x = v.x; r.y = v.y; return r; }
+    __device__ __forceinline__ rt_f4 sphere(uint32_t i) const { return lds_ld4(lds + pl.off_spheres + i); }
+    __device__ __forceinline__ void msphere(uint32_t i, rt_f4& m0, rt_f4& m1, rt_f4& m2) const {
+        lds_f4* m = lds + pl.off_mspheres + 3 * i; m0 = lds_ld4(m); m1 = lds_ld4(m + 1); m2 = lds_ld4(m + 2);
+    }
+    __device__ __forceinline__ void rect(uint32_t i, rt_f4& r0, rt_f4& r1) const { pair(pl.off_rects, i, r0, r1); }
+    __device__ __forceinline__ void box(uint32_t i, rt_f4& b0, rt_f4& b1) const { pair(pl.off_boxes, i, b0, b1); }
+    __device__ __forceinline__ void instance(uint32_t i, rt_f4& i0, rt_f4& i1) const { pair(pl.off_instances, i, i0, i1); }
+    __device__ __forceinline__ rt_i2 sphere_meta(uint32_t i) const { return meta(pl.off_sphere_meta, i); }
+    __device__ __forceinline__ rt_i2 msphere_meta(uint32_t i) const { return meta(pl.off_msphere_meta, i); }
+    __device__ __forceinline__ rt_i2 rect_meta(uint32_t i) const { return meta(pl.off_rect_meta, i); }
+    __device__ __forceinline__ rt_f4 op(int i) const { return lds_ld4(lds + pl.off_ops + i); }
+    __device__ __forceinline__ void material(int i, rt_f4& a0, rt_f4& a1) const { pair(pl.off_materials, (uint32_t)i, a0, a1); }
+    __device__ __forceinline__ void texture(int i, rt_f4& t0, rt_f4& t1) const { pair(pl.off_textures, (uint32_t)i, t0, t1); }
+    __device__ __forceinline__ rt_f4 medium(int m, int k) const { return lds_ld4(lds + pl.off_media + RT_MEDIUM_F4 * m + k); }
+    __device__ __forceinline__ rt_f4 get(int m, int k) const { return medium(m, k); }   // as a MediaSrc
+    __device__ __forceinline__ rt_f4 perlin_vec(int table, int h) const { return lds_ld4(lds + pl.off_perlin_vec + table * RT_PERLIN_VEC_F4 + h); }
+    __device__ __forceinline__ int perlin_perm(int table, int i) const { return ((lds_u8*)(lds + pl.off_perlin_perm))[table * RT_PERLIN_PERM_BYTES + i]; }
+};
+
+// The ray and hit records of 64 consecutive queue entries, copied by the memory pipeline straight into the wave's staging
+// area in LDS (global_load_lds_dwordx4: lane l's 16 bytes land at M0 + 16 l); no register is held while they travel.
+// Written as inline assembly on purpose: the compiler makes every later LDS read wait for a copy it knows to be in
+// flight (it cannot tell the tables from the staging area), which would stall the wave at its first table read.  The
+// caller waits with vmcnt(0) before it reads the staging area.
+__device__ __forceinline__ void shade_stage_one(const rt_f4* src, lds_f4* dst) {
+    uint32_t m0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)dst);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0), "v"(src) : "memory");
+}
+__device__ __forceinline__ void shade_stage(const rt_f4* ia, const rt_f4* ib, const rt_f4* ic, const rt_f4* hits, uint32_t i, lds_f4* stage) {
+    shade_stage_one(ia + i, stage);
+    shade_stage_one(ib + i, stage + 64);
+    shade_stage_one(ic + i, stage + 128);
+    shade_stage_one(hits + i, stage + 192);
+}
+
+// The same stage for scenes whose shading tables fit one CU's LDS: one 1024-thread block per CU copies them once; the
+// common path of a ray then has no dependent global-memory fetch at all, and the next 64 records of every wave travel
+// into LDS while the current ones are shaded.  The wave waits for them at the top of the next iteration, which costs
+// nothing when an append happened in between (it waited for all earlier memory operations already).
+__global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan pl, RtFrameDev fr, int bounce, uint32_t cap, const uint32_t* counts_in,
+                                                    uint32_t* counts_out, const rt_f4* ia, const rt_f4* ib, const rt_f4* ic,
+                                                    const rt_f4* hits, rt_f4* oa, rt_f4* ob, rt_f4* oc, rt_f4* contrib) {
+    const uint32_t n = counts_in[blockIdx.y * RT_COUNT_STRIDE];
+    if (blockIdx.x * 1024u >= n) return;
+    extern __shared__ __align__(16) unsigned char smem[];
+    {   // tables -> LDS
+        rt_f4* dst = reinterpret_cast<rt_f4*>(smem);
+        const int t = threadIdx.x;
+        for (int i = t; i < sc.n_spheres; i += 1024) dst[pl.off_spheres + i] = ld4(sc.spheres + i);
+        for (int i = t; i < sc.n_mspheres * 3; i += 1024) dst[pl.off_mspheres + i] = ld4(sc.mspheres + i);
+        for (int i = t; i < sc.n_rects * 2; i += 1024) dst[pl.off_rects + i] = ld4(sc.rects + i);
+        for (int i = t; i < sc.n_boxes * 2; i += 1024) dst[pl.off_boxes + i] = ld4(sc.boxes + i);
+        for (int i = t; i < sc.n_instances * 2; i += 1024) dst[pl.off_instances + i] = ld4(sc.instances + i);
+        for (int i = t; i < sc.n_ops; i += 1024) dst[pl.off_ops + i] = ld4(sc.ops + i);
+        for (int i = t; i < sc.n_materials * 2; i += 1024) dst[pl.off_materials + i] = ld4(sc.materials + i);
+        for (int i = t; i < sc.n_textures * 2; i += 1024) dst[pl.off_textures + i] = ld4(sc.textures + i);
+        for (int i = t; i < sc.n_media * RT_MEDIUM_F4; i += 1024) dst[pl.off_media + i] = ld4(sc.media + i);
+        for (int i = t; i < sc.n_perlin * RT_PERLIN_VEC_F4; i += 1024) dst[pl.off_perlin_vec + i] = ld4(sc.perlin_vec + i);
+        for (int i = t; i < sc.n_perlin * (RT_PERLIN_PERM_BYTES / 16); i += 1024) dst[pl.off_perlin_perm + i] = ld4(reinterpret_cast<const rt_f4*>(sc.perlin_perm) + i);
+        rt_i2* m;
+        m = reinterpret_cast<rt_i2*>(dst + pl.off_sphere_meta); for (int i = t; i < sc.n_spheres; i += 1024) m[i] = sc.sphere_meta[i];
+        m = reinterpret_cast<rt_i2*>(dst + pl.off_msphere_meta); for (int i = t; i < sc.n_mspheres; i += 1024) m[i] = sc.msphere_meta[i];
+        m = reinterpret_cast<rt_i2*>(dst + pl.off_rect_meta); for (int i = t; i < sc.n_rects; i += 1024) m[i] = sc.rect_meta[i];
+    }
+    __syncthreads();
+    ShadeTables tab; tab.lds = (lds_f4*)smem; tab.pl = pl;
+    const uint32_t out_shard = (blockIdx.x + blockIdx.y) % RT_SHARDS;
+    uint32_t* n_out_ptr = counts_out + out_shard * RT_COUNT_STRIDE;
+    ia += (size_t)blockIdx.y * cap; ib += (size_t)blockIdx.y * cap; ic += (size_t)blockIdx.y * cap; hits += (size_t)blockIdx.y * cap;
+    oa += (size_t)out_shard * cap; ob += (size_t)out_shard * cap; oc += (size_t)out_shard * cap;
+
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    lds_f4* stage = tab.lds + pl.off_stage + wave * 256u;
+    lds_u32* later = (lds_u32*)(tab.lds + pl.off_later) + wave * 128u;
+    const bool may_postpone = sc.n_perlin > 0;
+    const uint32_t stride = gridDim.x * 1024u;
+    uint32_t n_later = 0;                                              // wave-uniform
+    uint32_t base = blockIdx.x * 1024u + wave * 64u;                   // wave-uniform
+    if (base < n) shade_stage(ia, ib, ic, hits, min(base + lane, n - 1u), stage);
+    bool landed = false;                                               // the staged records are known to have arrived
+    for (; base < n; base += stride) {
+        const uint32_t i = base + lane;
+        if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        rt_f4 a = lds_ld4(stage + lane), b = lds_ld4(stage + 64 + lane), c = lds_ld4(stage + 128 + lane), h = lds_ld4(stage + 192 + lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the records are in registers, the staging area is free
+        if (base + stride < n) shade_stage(ia, ib, ic, hits, min(i + stride, n - 1u), stage);
+        ShadeOut out; shade_out_clear(out);
+        if (i < n) shade_ray<false>(sc, tab, tab, fr, bounce, a, b, c, h, may_postpone, contrib, nullptr, out);
+        landed = shade_append(out, n_out_ptr, cap, oa, ob, oc);
+        unsigned long long pm = __ballot(out.postponed);
+        if (pm) {
+            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+            if (out.postponed) later[n_later + rank] = i;
+            n_later += (uint32_t)__popcll(pm);
+            if (n_later >= 64u) {                                      // n_later < 128 always: at most 64 are added to < 64
+                n_later -= 64u;
+                __builtin_amdgcn_wave_barrier();
+                uint32_t j = later[n_later + lane];
+                ShadeOut o2; shade_out_clear(o2);
+                shade_ray<false>(sc, tab, tab, fr, bounce, ld4(ia + j), ld4(ib + j), ld4(ic + j), ld4(hits + j), false, contrib, nullptr, o2);
+                shade_append(o2, n_out_ptr, cap, oa, ob, oc);
+                landed = true;                                         // those loads were issued after the staging and have returned
+            }
+        }
+    }
+    if (n_later > 0) {
+        __builtin_amdgcn_wave_barrier();
+        uint32_t j = lane < n_later ? later[lane] : 0u;
+        ShadeOut o2; shade_out_clear(o2);
+        if (lane < n_later) shade_ray<false>(sc, tab, tab, fr, bounce, ld4(ia + j), ld4(ib + j), ld4(ic + j), ld4(hits + j), false, contrib, nullptr, o2);
+        shade_append(o2, n_out_ptr, cap, oa, ob, oc);
+    }
 }
 
 // accum[pixel] += sum over the pass's samples, in sample order (main.rs:585-589).
@@ -527,6 +638,9 @@ struct RtScene {
     double bvh_build_seconds = 0.0;        // device time of that build
     int top_first = 0;                     // first node of the region k_trace should keep in LDS (see plan_trace)
     int trace_block = 1024;                // threads per k_trace block (1024, or 256 where a block cannot have 160 KB of LDS)
+    bool shade_lds = false;                // the shading tables fit one CU's LDS: k_shade_lds instead of k_shade
+    RtShadePlan shade_plan;                // k_shade_lds: layout of the block's LDS
+    int shade_lds_bytes = 0;
 };
 
 // k_trace comes in two block shapes: 1024 threads (one block per CU; its 16 waves share one LDS copy of the scene) and,
@@ -617,6 +731,37 @@ static int plan_trace(RtScene* s) {
     return RT_OK;
 }
 
+// Decides whether the scene's shading tables, 4 KB of ray staging per wave and the lists of postponed hits fit the LDS of
+// one CU; then k_shade_lds replaces k_shade.
+static int plan_shade(RtScene* s) {
+    s->shade_lds = false;
+    if (const char* e = std::getenv("RT_SHADE_LDS")) { if (std::atoi(e) == 0) return RT_OK; }
+    const RtSceneView& v = s->view;
+    RtShadePlan& pl = s->shade_plan;
+    long used = 0;   // 16-byte records
+    auto place = [&](long n_records, int32_t& off) { off = (int32_t)used; used += n_records; };
+    place(16 * 4 * 64, pl.off_stage);   // first: its addresses then fit 16 bits, whatever width the copy instruction takes from M0
+    place(16 * 128 / 4, pl.off_later);
+    place(v.n_spheres, pl.off_spheres);                     place((v.n_spheres + 1) / 2, pl.off_sphere_meta);
+    place((long)v.n_mspheres * RT_MSPHERE_F4, pl.off_mspheres); place((v.n_mspheres + 1) / 2, pl.off_msphere_meta);
+    place((long)v.n_rects * RT_RECT_F4, pl.off_rects);      place((v.n_rects + 1) / 2, pl.off_rect_meta);
+    place((long)v.n_boxes * 2, pl.off_boxes);
+    place((long)v.n_instances * RT_INSTANCE_F4, pl.off_instances);
+    place(v.n_ops, pl.off_ops);
+    place((long)v.n_materials * RT_MATERIAL_F4, pl.off_materials);
+    place((long)v.n_textures * RT_TEXTURE_F4, pl.off_textures);
+    place((long)v.n_media * RT_MEDIUM_F4, pl.off_media);
+    place((long)v.n_perlin * RT_PERLIN_VEC_F4, pl.off_perlin_vec);
+    place((long)v.n_perlin * (RT_PERLIN_PERM_BYTES / 16), pl.off_perlin_perm);
+    if (used * 16 > 160 * 1024 - 512 || s->n_cu < RT_SHARDS) return RT_OK;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(used * 16)) != hipSuccess) {
+        (void)hipGetLastError();   // this device does not give one workgroup that much LDS
+        return RT_OK;
+    }
+    s->shade_lds = true; s->shade_lds_bytes = (int)(used * 16);
+    return RT_OK;
+}
+
 template <class T>
 static int upload(RtScene* s, const std::vector<T>& v, const T** out) {
     *out = nullptr;
@@ -644,7 +789,7 @@ static int ensure_workspace(RtScene* s, size_t n_paths) {
     if (!s->ev0) { HIP_TRY(hipEventCreate(&s->ev0)); HIP_TRY(hipEventCreate(&s->ev1)); }
     if (s->ws_paths >= n_paths) return RT_OK;
     free_workspace(s);
-    size_t cap = (n_paths + RT_SHARDS - 1) / RT_SHARDS + (size_t)RT_BLOCK * (RT_SHARDS + 2);
+    size_t cap = (n_paths + RT_SHARDS - 1) / RT_SHARDS + (size_t)1024 * (RT_SHARDS + 2);
     cap = (cap + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK;
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(hipMalloc((void**)&s->qa[i], cap * RT_SHARDS * sizeof(rt_f4)));
@@ -791,6 +936,7 @@ int rt_scene_create_ex(const RtBuilder* b, RtObj world, int device, int flags, R
         if ((r = upload(s, f.boxes, &v.boxes))) return r;
         s->view = v;
         if ((r = plan_trace(s))) return r;
+        if ((r = plan_shade(s))) return r;
         return RT_OK;
     }();
     if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
@@ -892,6 +1038,8 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         int gx = (int)std::min<size_t>(((size_t)n_paths / RT_SHARDS + RT_BLOCK - 1) / RT_BLOCK + 1, (size_t)grid_cap / RT_SHARDS);
         gx = std::max(RT_SHARDS, (gx + RT_SHARDS - 1) / RT_SHARDS * RT_SHARDS);
         dim3 bgrid((unsigned)gx, RT_SHARDS);
+        // k_shade_lds: one 1024-thread block per CU, also a multiple of RT_SHARDS blocks per region
+        dim3 lgrid((unsigned)std::max(RT_SHARDS, s->n_cu / RT_SHARDS / RT_SHARDS * RT_SHARDS), RT_SHARDS);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(s->ev0, st));
         for (int b = 1; b <= p->max_depth; ++b) {
@@ -905,6 +1053,9 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
             if (instrumented)
                 hipLaunchKernelGGL(k_shade<true>, bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, cin, cout, s->qa[in], s->qb[in], s->qc[in], s->hits,
                                    s->qa[outq], s->qb[outq], s->qc[outq], s->contrib, s->work);
+            else if (s->shade_lds)
+                hipLaunchKernelGGL(k_shade_lds, lgrid, dim3(1024), (size_t)s->shade_lds_bytes, st, s->view, s->shade_plan, fr, b, cap, cin, cout,
+                                   s->qa[in], s->qb[in], s->qc[in], s->hits, s->qa[outq], s->qb[outq], s->qc[outq], s->contrib);
             else
                 hipLaunchKernelGGL(k_shade<false>, bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, cin, cout, s->qa[in], s->qb[in], s->qc[in], s->hits,
                                    s->qa[outq], s->qb[outq], s->qc[outq], s->contrib, s->work);
@@ -940,11 +1091,9 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         HIP_TRY(hipMemcpy(w, s->work, sizeof(w), hipMemcpyDeviceToHost));
         for (int i = 0; i < 16; ++i) local.work[i] = w[i];
     }
-    if (debug_work) {   // developer output: wave-level counters of the instrumented k_trace, section clocks of a -DRT_SHADE_CLOCK build
+    if (debug_work) {   // developer output: wave-level counters of the instrumented k_trace
         unsigned long long w2[16];
         HIP_TRY(hipMemcpy(w2, s->work + 16, sizeof(w2), hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "k_shade wave clocks: load+philox %llu media %llu surface %llu scatter %llu contrib %llu append %llu\n",
-                     w2[4], w2[5], w2[6], w2[7], w2[8], w2[9]);
         std::fprintf(stderr, "k_trace wave counters: outer %llu refills %llu node-iters %llu leaf-iters %llu\n", w2[0], w2[1], w2[2], w2[3]);
     }
     local.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();

@@ -313,6 +313,21 @@ struct RtGlobalPrims {
     }
 };
 
+// Everything shading reads besides the ray and its hit: the primitive records above plus their (material, object id)
+// pairs, instance ops, materials, textures, medium records and Perlin tables.  This one reads global memory; the
+// shading kernel for small scenes has its own that serves a copy in LDS.
+struct RtGlobalTables : RtGlobalPrims {
+    RT_HDM rt_i2 sphere_meta(uint32_t i) const { return sc->sphere_meta[i]; }
+    RT_HDM rt_i2 msphere_meta(uint32_t i) const { return sc->msphere_meta[i]; }
+    RT_HDM rt_i2 rect_meta(uint32_t i) const { return sc->rect_meta[i]; }
+    RT_HDM rt_f4 op(int i) const { return ld4(sc->ops + i); }
+    RT_HDM void material(int i, rt_f4& a0, rt_f4& a1) const { a0 = ld4(sc->materials + 2 * (size_t)i); a1 = ld4(sc->materials + 2 * (size_t)i + 1); }
+    RT_HDM void texture(int i, rt_f4& t0, rt_f4& t1) const { t0 = ld4(sc->textures + 2 * (size_t)i); t1 = ld4(sc->textures + 2 * (size_t)i + 1); }
+    RT_HDM rt_f4 medium(int m, int k) const { return ld4(sc->media + RT_MEDIUM_F4 * (size_t)m + k); }
+    RT_HDM rt_f4 perlin_vec(int table, int h) const { return ld4(sc->perlin_vec + (size_t)table * RT_PERLIN_VEC_F4 + h); }
+    RT_HDM int perlin_perm(int table, int i) const { return sc->perlin_perm[(size_t)table * RT_PERLIN_PERM_BYTES + i]; }
+};
+
 RT_HD bool rt_is_inner(int32_t cur) { return (uint32_t)cur < (uint32_t)RT_SENTINEL; }
 
 RT_HD void rt_trav_begin(const RtSceneView& sc, v3 wo, v3 wd, RtTrav& tv) {
@@ -581,38 +596,40 @@ RT_HD void rt_sphere_uv(v3 n, float* u, float* v) {  // objects.rs:179-193
     *u = phi * 0.15915494309189535f; *v = theta * 0.3183098861837907f;
 }
 
-RT_HD void rt_surface(const RtSceneView& sc, v3 wo, v3 wd, float time, const RtHit& h, bool want_uv, RtSurface& s) {
+// Tab: see RtGlobalTables.
+template <class Tab>
+RT_HD void rt_surface(const Tab& tab, v3 wo, v3 wd, float time, const RtHit& h, bool want_uv, RtSurface& s) {
     uint32_t kind = RT_HIT_KIND(h.code), idx = RT_HIT_INDEX(h.code);
     s.u = 0.0f; s.v = 0.0f;
     if (kind == RT_KIND_MEDIUM) {  // mediums.rs:69-80
-        const rt_f4* md = sc.media + RT_MEDIUM_F4 * (size_t)idx;
         s.p = fma3(h.t, wd, wo);
         s.front = wd.x < 0.0f;
         s.n = mk3(s.front ? 1.0f : -1.0f, 0.0f, 0.0f);
-        s.mat = f2i(ld4(md + 1).w); s.id = f2i(ld4(md + 3).w);
+        s.mat = f2i(tab.medium((int)idx, 1).w); s.id = f2i(tab.medium((int)idx, 3).w);
         return;
     }
     v3 o = wo, d = wd;
     rt_f4 i0, i1;
     if (h.inst >= 0) {
-        i0 = ld4(sc.instances + 2 * (size_t)h.inst); i1 = ld4(sc.instances + 2 * (size_t)h.inst + 1);
+        tab.instance((uint32_t)h.inst, i0, i1);
         o = rt_to_object_point(i0, i1, wo); d = rt_to_object_dir(i0, wd);
     }
     v3 p = fma3(h.t, d, o), on;
     rt_i2 meta;
     if (kind == RT_KIND_SPHERE) {
-        rt_f4 sp = ld4(sc.spheres + idx);
+        rt_f4 sp = tab.sphere(idx);
         on = normalize3(rt_rcp(sp.w) * (p - mk3(sp.x, sp.y, sp.z)));  // objects.rs:226
-        meta = sc.sphere_meta[idx];
+        meta = tab.sphere_meta(idx);
         if (want_uv) rt_sphere_uv(on, &s.u, &s.v);
     } else if (kind == RT_KIND_MSPHERE) {
-        const rt_f4* m = sc.mspheres + 3 * (size_t)idx;
-        rt_f4 m0 = ld4(m), m1 = ld4(m + 1), m2 = ld4(m + 2);
+        rt_f4 m0, m1, m2;
+        tab.msphere(idx, m0, m1, m2);
         on = normalize3(rt_rcp(m0.w) * (p - rt_msphere_center(m0, m1, m2, time)));  // objects.rs:313
-        meta = sc.msphere_meta[idx];
+        meta = tab.msphere_meta(idx);
         if (want_uv) rt_sphere_uv(on, &s.u, &s.v);
     } else if (kind == RT_KIND_BOX) {  // side `idx & 7` of box `idx >> 3`, as the rectangle objects.rs:445-500 builds
-        rt_f4 b0 = ld4(sc.boxes + 2 * (size_t)(idx >> 3)), b1 = ld4(sc.boxes + 2 * (size_t)(idx >> 3) + 1);
+        rt_f4 b0, b1;
+        tab.box(idx >> 3, b0, b1);
         int face = (int)(idx & 7u), type = face >> 1;   // 0 = Xy, 1 = Xz, 2 = Yz
         on = type == 0 ? mk3(0, 0, 1) : (type == 1 ? mk3(0, 1, 0) : mk3(1, 0, 0));
         meta.x = f2i(b0.w); meta.y = f2i(b1.w) + face;
@@ -622,10 +639,11 @@ RT_HD void rt_surface(const RtSceneView& sc, v3 wo, v3 wd, float time, const RtH
             s.u = (x - xa) * rt_rcp(xb - xa); s.v = (y - ya) * rt_rcp(yb - ya);
         }
     } else {
-        rt_f4 r0 = ld4(sc.rects + 2 * (size_t)idx), r1 = ld4(sc.rects + 2 * (size_t)idx + 1);
+        rt_f4 r0, r1;
+        tab.rect(idx, r0, r1);
         int type = f2i(r1.y);
         on = type == 0 ? mk3(0, 0, 1) : (type == 1 ? mk3(0, 1, 0) : mk3(1, 0, 0));  // objects.rs:385-389
-        meta = sc.rect_meta[idx];
+        meta = tab.rect_meta(idx);
         if (want_uv) {
             float x = type == 2 ? p.y : p.x, y = type == 0 ? p.y : p.z;
             s.u = (x - r0.x) * rt_rcp(r0.y - r0.x); s.v = (y - r0.z) * rt_rcp(r0.w - r0.z);  // objects.rs:399-400
@@ -638,7 +656,7 @@ RT_HD void rt_surface(const RtSceneView& sc, v3 wo, v3 wd, float time, const RtH
         // rebuilds the record from the ray on its inner side and the rotated, already flipped normal.
         int first = f2i(i1.z), count = f2i(i1.w);
         for (int k = count - 1; k >= 0; --k) {
-            rt_f4 op = ld4(sc.ops + first + k);
+            rt_f4 op = tab.op(first + k);
             if (f2i(op.w) == RT_OP_TRANSLATE) { p = p + mk3(op.x, op.y, op.z); continue; }
             float c = op.x, sn = op.y;
             p = mk3(fmaf(c, p.x, sn * p.z), p.y, fmaf(-sn, p.x, c * p.z));
@@ -650,9 +668,14 @@ RT_HD void rt_surface(const RtSceneView& sc, v3 wo, v3 wd, float time, const RtH
     }
     s.p = p; s.n = n; s.front = front; s.mat = meta.x; s.id = meta.y;
 }
+RT_HD void rt_surface(const RtSceneView& sc, v3 wo, v3 wd, float time, const RtHit& h, bool want_uv, RtSurface& s) {
+    RtGlobalTables g; g.sc = &sc;
+    rt_surface(g, wo, wd, time, h, want_uv, s);
+}
 
 // ------------------------------------------------------------------ textures (textures.rs)
-RT_HD float rt_perlin_noise(const rt_f4* vec, const uint8_t* perm, v3 p) {  // textures.rs:146-170, 214-237
+template <class Tab>
+RT_HD float rt_perlin_noise(const Tab& tab, int table, v3 p) {  // textures.rs:146-170, 214-237
     float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
     float u = p.x - fx, v = p.y - fy, w = p.z - fz;
     int i = (int)fx, j = (int)fy, k = (int)fz;
@@ -664,23 +687,27 @@ RT_HD float rt_perlin_noise(const rt_f4* vec, const uint8_t* perm, v3 p) {  // t
         for (int dj = 0; dj < 2; ++dj)
 #pragma unroll
             for (int dk = 0; dk < 2; ++dk) {
-                int h = perm[(i + di) & 255] ^ perm[256 + ((j + dj) & 255)] ^ perm[512 + ((k + dk) & 255)];
-                rt_f4 c = ld4(vec + h);
+                int h = tab.perlin_perm(table, (i + di) & 255) ^ tab.perlin_perm(table, 256 + ((j + dj) & 255)) ^
+                        tab.perlin_perm(table, 512 + ((k + dk) & 255));
+                rt_f4 c = tab.perlin_vec(table, h);
                 float wgt = (di ? uu : 1.0f - uu) * (dj ? vv : 1.0f - vv) * (dk ? ww : 1.0f - ww);
                 accum = fmaf(wgt, fmaf(c.x, u - (float)di, fmaf(c.y, v - (float)dj, c.z * (w - (float)dk))), accum);
             }
     return accum;
 }
-RT_HD float rt_turbulence(const rt_f4* vec, const uint8_t* perm, v3 p) {  // textures.rs:131-143
+template <class Tab>
+RT_HD float rt_turbulence(const Tab& tab, int table, v3 p) {  // textures.rs:131-143
     float accum = 0.0f, weight = 1.0f;
-    for (int i = 0; i < 7; ++i) { accum = fmaf(weight, rt_perlin_noise(vec, perm, p), accum); weight *= 0.5f; p = 2.0f * p; }
+    for (int i = 0; i < 7; ++i) { accum = fmaf(weight, rt_perlin_noise(tab, table, p), accum); weight *= 0.5f; p = 2.0f * p; }
     return fabsf(accum);
 }
 // `inline_rgb` is the colour baked into the material record when its texture is a SolidColor (tex < 0).
-RT_HD v3 rt_texture_value(const RtSceneView& sc, int tex, v3 inline_rgb, v3 p) {
+template <class Tab>
+RT_HD v3 rt_texture_value(const Tab& tab, int tex, v3 inline_rgb, v3 p) {
     if (tex < 0) return inline_rgb;
     for (int it = 0; it < 16; ++it) {
-        rt_f4 t0 = ld4(sc.textures + 2 * (size_t)tex), t1 = ld4(sc.textures + 2 * (size_t)tex + 1);
+        rt_f4 t0, t1;
+        tab.texture(tex, t0, t1);
         int type = f2i(t0.x);
         if (type == RT_TEX_CHECKER) {  // textures.rs:60-69
             float sines = sinf(10.0f * p.x) * sinf(10.0f * p.y) * sinf(10.0f * p.z);
@@ -689,8 +716,7 @@ RT_HD v3 rt_texture_value(const RtSceneView& sc, int tex, v3 inline_rgb, v3 p) {
         }
         if (type == RT_TEX_NOISE) {  // textures.rs:87-96
             int table = f2i(t0.y);
-            float turb = rt_turbulence(sc.perlin_vec + (size_t)table * RT_PERLIN_VEC_F4,
-                                       sc.perlin_perm + (size_t)table * RT_PERLIN_PERM_BYTES, t1.x * p);
+            float turb = rt_turbulence(tab, table, t1.x * p);
             float s = 0.5f * (1.0f + sinf(fmaf(10.0f, turb, t1.x * p.z)));
             return mk3(s, s, s);
         }
@@ -704,9 +730,11 @@ RT_HD v3 rt_reflect(v3 v, v3 n) { return fma3(-2.0f * dot3(v, n), n, v); }  // u
 
 // One scatter event (lib.rs:64-65).  u1, u2: the bounce's two draws (unit vector; a dielectric decides on u1).
 // Returns true when the path continues along `dir` with throughput *= atten.
-RT_HD bool rt_scatter(const RtSceneView& sc, const RtSurface& s, v3 wd, float u1, float u2,
+template <class Tab>
+RT_HD bool rt_scatter(const Tab& tab, const RtSurface& s, v3 wd, float u1, float u2,
                       v3& atten, v3& dir, v3& emitted) {
-    rt_f4 a0 = ld4(sc.materials + 2 * (size_t)s.mat), a1 = ld4(sc.materials + 2 * (size_t)s.mat + 1);
+    rt_f4 a0, a1;
+    tab.material(s.mat, a0, a1);
     int type = f2i(a0.x), tex = f2i(a0.y);
     v3 rgb = mk3(a1.x, a1.y, a1.z);
     emitted = mk3(0, 0, 0);
@@ -715,7 +743,7 @@ RT_HD bool rt_scatter(const RtSceneView& sc, const RtSurface& s, v3 wd, float u1
     if (type == RT_MAT_LAMBERTIAN) {  // materials.rs:77-90
         dir = s.n + rt_unit_vector(u1, u2);
         if (dot3(dir, dir) < 1e-16f) dir = s.n;
-        atten = rt_texture_value(sc, tex, rgb, s.p);
+        atten = rt_texture_value(tab, tex, rgb, s.p);
         return true;
     }
     if (type == RT_MAT_METAL) {  // materials.rs:129-145
@@ -741,11 +769,15 @@ RT_HD bool rt_scatter(const RtSceneView& sc, const RtSurface& s, v3 wd, float u1
         return true;
     }
     if (type == RT_MAT_LIGHT) {  // materials.rs:243-249
-        emitted = rt_texture_value(sc, tex, rgb, s.p);
+        emitted = rt_texture_value(tab, tex, rgb, s.p);
         return false;
     }
     // Isotropic, materials.rs:276-283
     dir = rt_unit_vector(u1, u2);
-    atten = rt_texture_value(sc, tex, rgb, s.p);
+    atten = rt_texture_value(tab, tex, rgb, s.p);
     return true;
+}
+RT_HD bool rt_scatter(const RtSceneView& sc, const RtSurface& s, v3 wd, float u1, float u2, v3& atten, v3& dir, v3& emitted) {
+    RtGlobalTables g; g.sc = &sc;
+    return rt_scatter(g, s, wd, u1, u2, atten, dir, emitted);
 }

@@ -112,10 +112,11 @@ def test_synthetic_sphere_field_matches_oracle(gpu_required):
     scene.close()
 
 
-@pytest.mark.parametrize("env", [{"RT_TRACE_WIDE_STACK": "1"}, {"RT_TRACE_BLOCK": "256"}])
-@pytest.mark.parametrize("name", ["cornell.yml", "final_scene.yml"])
-def test_trace_kernel_variants_agree(gpu_required, name, env):
-    """k_trace picks its block shape, stack form and what lives in LDS per scene; every choice must give the very same image."""
+@pytest.mark.parametrize("env", [{"RT_TRACE_WIDE_STACK": "1"}, {"RT_TRACE_BLOCK": "256"}, {"RT_SHADE_LDS": "0"}])
+@pytest.mark.parametrize("name", ["cornell.yml", "final_scene.yml", "showcase.yml"])
+def test_kernel_variants_agree(gpu_required, name, env):
+    """k_trace picks its block shape, stack form and what lives in LDS per scene, and shading runs either from tables in LDS
+    with staged ray records (k_shade_lds) or from global memory (k_shade); every choice must give the very same image."""
     cfg, cam = config_camera(name)
     p = rt.render_params(200, 200, 4, cfg.max_depth, RENDER_SEED)
 
