@@ -11,6 +11,7 @@
 // primitives, which the kernels test after the surface hit is known.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include "scene_builder.h"
@@ -423,7 +424,10 @@ private:
                 }
             }
             if (best_axis >= 0) {
-                double leaf_cost = (double)n * bx.area(), split_cost = bx.area() + best;
+                // cost of testing one primitive of the leaf's kind, in node steps of k_trace (measured on final_scene.yml
+                // and cornell.yml: the f64 sphere test and the box test weigh about two node steps, a rectangle one)
+                const double prim = items[lo].cls == RT_KIND_RECT ? 1.0 : 2.0;
+                double leaf_cost = prim * (double)n * bx.area(), split_cost = bx.area() + prim * best;
                 if (can_leaf && leaf_cost <= split_cost) return make_leaf(items, lo, hi);
                 double ext = cb.mx[best_axis] - cb.mn[best_axis], mnv = cb.mn[best_axis];
                 auto it = std::partition(items.begin() + lo, items.begin() + hi, [&](const Item& x) {
