@@ -367,22 +367,10 @@ RT_HD void rt_sentinel_step(v3 wo, v3 wd, RtTrav& tv, Stack& stk) {
     tv.cur = rt_pop(tv, stk);
 }
 
-// tv.cur is a leaf code (< 0): enter the instance, or intersect the leaf's primitives; then pop.
-template <bool STATS, class Prims, class Stack>
-RT_HD void rt_leaf_step(const Prims& prims, v3 wo, v3 wd, float time, float tmin, uint32_t src, RtTrav& tv, RtHit& hit,
-                        Stack& stk, RtCounters* wc) {
-    uint32_t x = ~(uint32_t)tv.cur;
-    if (x & RT_LEAF_INSTANCE_BIT) {
-        int32_t ii = (int32_t)(x & 0x3FFFFFFFu);
-        rt_f4 i0, i1;
-        prims.instance((uint32_t)ii, i0, i1);
-        if (tv.sp < stk.cap()) stk.put_sentinel(tv.sp++);
-        tv.inst = ii;
-        if (STATS) wc->instances++;
-        rt_trav_ray(tv, rt_to_object_point(i0, i1, wo), rt_to_object_dir(i0, wd));
-        tv.cur = f2i(i1.y);
-        return;
-    }
+// `leaf` is the code of a primitive leaf (< 0, not an instance): intersect its primitives with the ray held in tv.
+template <bool STATS, class Prims>
+RT_HD void rt_leaf_test(const Prims& prims, int32_t leaf, float time, float tmin, uint32_t src, const RtTrav& tv, RtHit& hit, RtCounters* wc) {
+    uint32_t x = ~(uint32_t)leaf;
     uint32_t kind = (x >> 28) & 3u, cnt = ((x >> 26) & 3u) + 1u, first = x & 0x03FFFFFFu;
     for (uint32_t k = 0; k < cnt; ++k) {
         uint32_t idx = first + k, code = RT_HIT_CODE(kind, idx);
@@ -416,6 +404,27 @@ RT_HD void rt_leaf_step(const Prims& prims, v3 wo, v3 wd, float time, float tmin
         }
         if (t < hit.t) { hit.t = t; hit.code = code; hit.inst = tv.inst; }  // false for NaN
     }
+}
+
+// tv.cur is an instance leaf: push the sentinel, take the ray to the instance's object space, go to its root.
+template <bool STATS, class Prims, class Stack>
+RT_HD void rt_instance_enter(const Prims& prims, v3 wo, v3 wd, RtTrav& tv, Stack& stk, RtCounters* wc) {
+    int32_t ii = (int32_t)(~(uint32_t)tv.cur & 0x3FFFFFFFu);
+    rt_f4 i0, i1;
+    prims.instance((uint32_t)ii, i0, i1);
+    if (tv.sp < stk.cap()) stk.put_sentinel(tv.sp++);
+    tv.inst = ii;
+    if (STATS) wc->instances++;
+    rt_trav_ray(tv, rt_to_object_point(i0, i1, wo), rt_to_object_dir(i0, wd));
+    tv.cur = f2i(i1.y);
+}
+
+// tv.cur is a leaf code (< 0): enter the instance, or intersect the leaf's primitives; then pop.
+template <bool STATS, class Prims, class Stack>
+RT_HD void rt_leaf_step(const Prims& prims, v3 wo, v3 wd, float time, float tmin, uint32_t src, RtTrav& tv, RtHit& hit,
+                        Stack& stk, RtCounters* wc) {
+    if (~(uint32_t)tv.cur & RT_LEAF_INSTANCE_BIT) { rt_instance_enter<STATS>(prims, wo, wd, tv, stk, wc); return; }
+    rt_leaf_test<STATS>(prims, tv.cur, time, tmin, src, tv, hit, wc);
     tv.cur = rt_pop(tv, stk);
 }
 
