@@ -528,6 +528,63 @@ struct RtGlobalMedia {
     const rt_f4* media;
     RT_HDM rt_f4 get(int m, int k) const { return ld4(media + RT_MEDIUM_F4 * (size_t)m + k); }
 };
+// The two crossings t1 <= t2 of the whole ray line with the boundary of medium m (mediums.rs:46-47); false when the
+// ray misses the boundary or there is no second crossing.
+template <class MediaSrc>
+RT_HD bool rt_medium_span(const RtSceneView& sc, const MediaSrc& msrc, int m, v3 wo, v3 wd, float time, float& t1, float& t2) {
+    rt_f4 m5 = msrc.get(m, 5);
+    const int fast = rt_uniform(f2i(m5.x));
+    v3 o = wo, d = wd;
+    if (fast != 0) {
+        // the boundary is one convex primitive: its two crossings are the entry and the exit (mediums.rs:46-47)
+        if (rt_uniform(f2i(m5.y)) != 0) {
+            rt_f4 i0 = msrc.get(m, 8), i1 = msrc.get(m, 9);
+            o = rt_to_object_point(i0, i1, wo); d = rt_to_object_dir(i0, wd);
+        }
+        rt_f4 p0 = msrc.get(m, 6);
+        if (fast == 1) {
+            if (!rt_sphere_roots(mk3(p0.x, p0.y, p0.z), p0.w, o, d, t1, t2)) return false;
+        } else {
+            rt_f4 p1 = msrc.get(m, 7);
+            int f_in, f_out;
+            if (!rt_box_slabs(p0, p1, o, d, mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z)), t1, t2, f_in, f_out)) return false;
+        }
+        return !(t2 < t1 + fmaxf(0.0001f, 1e-6f * fabsf(t1)));                        // coincident crossings: no second one
+    }
+    rt_f4 m2 = msrc.get(m, 2), m3 = msrc.get(m, 3), m4 = msrc.get(m, 4);
+    int ii = rt_uniform(f2i(m2.x));
+    if (ii >= 0) {
+        rt_f4 i0 = ld4(sc.instances + 2 * (size_t)ii), i1 = ld4(sc.instances + 2 * (size_t)ii + 1);
+        o = rt_to_object_point(i0, i1, wo); d = rt_to_object_dir(i0, wd);
+    }
+    rt_boundary_pair(sc, m2, m3, m4, o, d, time, t1, t2);                           // mediums.rs:46-47
+    if (!(t1 < rt_inf())) return false;
+    // The re-query offset 0.0001 vanishes in fp32 once |t1| exceeds ~1000 (the r = 5000 fog), so it is widened
+    // to a few ulps of t1 when that is larger.
+    float t_next = t1 + fmaxf(0.0001f, 1e-6f * fabsf(t1));
+    if (t2 < t_next) t2 = rt_boundary_hit(sc, m2, m3, m4, o, d, time, t_next, rt_inf());
+    return t2 < rt_inf();                                                            // also false for NaN (no second crossing)
+}
+
+// Free flight through medium m along the ray, limited by t_limit (the closest hit so far): the ray parameter of the
+// collision, or NaN when the ray does not collide in this medium.  `draw` = the medium's 32 random bits for this segment.
+template <class MediaSrc>
+RT_HD float rt_medium_collision(const RtSceneView& sc, const MediaSrc& msrc, int m, v3 wo, v3 wd, v3 winv, float len, float time, float tmin,
+                                float t_limit, uint32_t draw) {
+    rt_f4 m0 = msrc.get(m, 0), m1 = msrc.get(m, 1);
+    if (!(rt_slab(m0.x, m0.y, m0.z, m1.x, m1.y, m1.z, wo, winv, tmin, t_limit) < rt_inf())) return rt_nan();
+    float t1, t2;
+    if (!rt_medium_span(sc, msrc, m, wo, wd, time, t1, t2)) return rt_nan();
+    if (t1 < tmin) t1 = tmin;
+    if (t2 > t_limit) t2 = t_limit;
+    if (t1 >= t2) return rt_nan();
+    if (t1 < 0.0f) t1 = 0.0f;
+    float inside = (t2 - t1) * len;
+    float hit_dist = m0.w * rt_log10(rt_u24(draw));                                 // mediums.rs:64 (log base 10)
+    if (hit_dist > inside) return rt_nan();
+    return t1 + hit_dist * rt_rcp(len);
+}
+
 template <class MediaSrc>
 RT_HD void rt_media_hits(const RtSceneView& sc, const MediaSrc& msrc, v3 wo, v3 wd, float time, float tmin, uint32_t pixel, uint32_t sample,
                          uint32_t bounce, uint32_t key0, uint32_t key1, const uint32_t rnd0[4], RtHit& hit) {
@@ -541,53 +598,10 @@ RT_HD void rt_media_hits(const RtSceneView& sc, const MediaSrc& msrc, v3 wo, v3 
             rt_philox(pixel, sample, bounce, (uint32_t)(k >> 2), key0, key1, nr);
             r0 = nr[0]; r1 = nr[1]; r2 = nr[2]; r3 = nr[3];
         }
-        rt_f4 m0 = msrc.get(m, 0), m1 = msrc.get(m, 1);
-        if (!(rt_slab(m0.x, m0.y, m0.z, m1.x, m1.y, m1.z, wo, winv, tmin, hit.t) < rt_inf())) continue;
-        rt_f4 m5 = msrc.get(m, 5);
-        const int fast = rt_uniform(f2i(m5.x));
-        v3 o = wo, d = wd;
-        float t1, t2;
-        if (fast != 0) {
-            // the boundary is one convex primitive: its two crossings are the entry and the exit (mediums.rs:46-47)
-            if (rt_uniform(f2i(m5.y)) != 0) {
-                rt_f4 i0 = msrc.get(m, 8), i1 = msrc.get(m, 9);
-                o = rt_to_object_point(i0, i1, wo); d = rt_to_object_dir(i0, wd);
-            }
-            rt_f4 p0 = msrc.get(m, 6);
-            if (fast == 1) {
-                if (!rt_sphere_roots(mk3(p0.x, p0.y, p0.z), p0.w, o, d, t1, t2)) continue;
-            } else {
-                rt_f4 p1 = msrc.get(m, 7);
-                int f_in, f_out;
-                if (!rt_box_slabs(p0, p1, o, d, mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z)), t1, t2, f_in, f_out)) continue;
-            }
-            if (t2 < t1 + fmaxf(0.0001f, 1e-6f * fabsf(t1))) continue;                  // coincident crossings: no second one
-        } else {
-            rt_f4 m2 = msrc.get(m, 2), m3 = msrc.get(m, 3), m4 = msrc.get(m, 4);
-            int ii = rt_uniform(f2i(m2.x));
-            if (ii >= 0) {
-                rt_f4 i0 = ld4(sc.instances + 2 * (size_t)ii), i1 = ld4(sc.instances + 2 * (size_t)ii + 1);
-                o = rt_to_object_point(i0, i1, wo); d = rt_to_object_dir(i0, wd);
-            }
-            rt_boundary_pair(sc, m2, m3, m4, o, d, time, t1, t2);                       // mediums.rs:46-47
-            if (!(t1 < rt_inf())) continue;
-            // The re-query offset 0.0001 vanishes in fp32 once |t1| exceeds ~1000 (the r = 5000 fog), so it is widened
-            // to a few ulps of t1 when that is larger.
-            float t_next = t1 + fmaxf(0.0001f, 1e-6f * fabsf(t1));
-            if (t2 < t_next) t2 = rt_boundary_hit(sc, m2, m3, m4, o, d, time, t_next, rt_inf());
-            if (!(t2 < rt_inf())) continue;                                         // also false for NaN (no second crossing)
-        }
-        if (t1 < tmin) t1 = tmin;
-        if (t2 > hit.t) t2 = hit.t;
-        if (t1 >= t2) continue;
-        if (t1 < 0.0f) t1 = 0.0f;
-        float inside = (t2 - t1) * len;
         int lane4 = k & 3;
         uint32_t draw = lane4 == 0 ? r0 : (lane4 == 1 ? r1 : (lane4 == 2 ? r2 : r3));
-        float hit_dist = m0.w * rt_log10(rt_u24(draw));                             // mediums.rs:64 (log base 10)
-        if (hit_dist > inside) continue;
-        float t = t1 + hit_dist * rt_rcp(len);
-        if (t < hit.t) { hit.t = t; hit.code = RT_HIT_CODE(RT_KIND_MEDIUM, (uint32_t)m); hit.inst = -1; }
+        float t = rt_medium_collision(sc, msrc, m, wo, wd, winv, len, time, tmin, hit.t, draw);
+        if (t < hit.t) { hit.t = t; hit.code = RT_HIT_CODE(RT_KIND_MEDIUM, (uint32_t)m); hit.inst = -1; }   // false for NaN
     }
 }
 RT_HD void rt_media_hits(const RtSceneView& sc, v3 wo, v3 wd, float time, float tmin, uint32_t pixel, uint32_t sample,

@@ -2,7 +2,7 @@
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tr = [r for r in rows if r["Kernel_Name"].startswith("void k_trace")]
-sh = [r for r in rows if r["Kernel_Name"].startswith("void k_shade")]
+sh = [r for r in rows if (r["Kernel_Name"].startswith("void k_shade") or r["Kernel_Name"].startswith("k_shade_lds"))]
 d = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 tr, sh = tr[-n:], sh[-n:]
