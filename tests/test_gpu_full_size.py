@@ -140,6 +140,36 @@ def test_kernel_variants_agree(gpu_required, name, env):
     assert rays2 == rays and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("size", [(37, 29), (131, 7), (2, 2), (260, 251)])
+def test_shading_kernels_agree_on_ragged_sizes(gpu_required, size):
+    """k_shade_lds stages 64 queue entries per wave and clamps its last batch to the queue end; k_shade reads entry by entry.
+    Queue lengths that are a multiple of nothing, single-ray queues and passes of a few hundred paths must give the same image."""
+    W, H = size
+    cfg, cam = config_camera("final_scene.yml")
+    cam = rt.make_camera((478, 278, -600), (278, 278, 0), (0, 1, 0), 40.0, W / H, 0.0, 10.0)
+    b = rt.Builder()
+    world = b.scene_from_config(os.path.join(CONFIGS, "final_scene.yml"), SCENE_SEED)
+    images = []
+    for lds in ("1", "0"):
+        old = os.environ.get("RT_SHADE_LDS")
+        os.environ["RT_SHADE_LDS"] = lds
+        try:
+            scene = rt.Scene(b, world, 0)
+            one, _, st1 = scene.render(cam, rt.render_params(W, H, 5, cfg.max_depth, RENDER_SEED))
+            many, _, st2 = scene.render(cam, rt.render_params(W, H, 5, cfg.max_depth, RENDER_SEED, paths_per_pass=max(1, W * H * 2)))
+            scene.close()
+        finally:
+            if old is None:
+                os.environ.pop("RT_SHADE_LDS", None)
+            else:
+                os.environ["RT_SHADE_LDS"] = old
+        assert st2.passes == 3 and st1.rays == st2.rays
+        np.testing.assert_allclose(many, one, rtol=1e-5, atol=1e-6)   # pass boundaries only change the fp32 summation order
+        images.append((one, many, st1.rays))
+    assert images[0][2] == images[1][2]
+    assert np.array_equal(images[0][0], images[1][0]) and np.array_equal(images[0][1], images[1][1])
+
+
 def test_cli_checkpoint_and_resume(gpu_required, tmp_path):
     """rt_cli renders in passes with --checkpoint, continues an existing checkpoint, and writes PNG by extension."""
     import subprocess
