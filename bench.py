@@ -166,6 +166,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload.replace(".yml", ""))
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        issue = None   # VALU issue figures of the same workload from the committed PMC passes (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, ...)
+        vpath = os.path.join(ROOT, "profiles", "valu_%s.json" % args.workload.replace(".yml", ""))
+        if os.path.exists(vpath):
+            issue = json.load(open(vpath)).get("kernels", {}).get("k_trace")
         paths = cfg.image_width * cfg.image_height * args.spp_per_step * world
         out = {
             "metric": "Mrays/sec (whole node)", "value": main_run["total_rays"] / main_run["dt"] / 1e6, "unit": "Mrays/s",
@@ -187,7 +191,7 @@ def main():
                                  "by VALU instruction issue of divergent traversal at partial lane occupancy (the fp32 FLOP rate of "
                                  "roofline_valu counts live lanes only), not by HBM"},
             "roofline_valu": {"kernel": "k_trace", "bound": "valu_fp32", "achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": tfl / VALU_PEAK_TFLOPS, "flops_per_ray": tr_flops},
+                              "frac": tfl / VALU_PEAK_TFLOPS, "flops_per_ray": tr_flops, "issue": issue},
             "bounce_total": {"kernels": "k_trace + k_shade", "ms": main_run["kernel_ms"], "launch_pairs": main_run["launches"],
                              "flops_per_ray": flops_per_ray, "bytes_per_ray": bytes_per_ray,
                              "achieved_gbs": bytes_per_ray * rays0 / b_s / 1e9, "achieved_tflops": flops_per_ray * rays0 / b_s / 1e12},
