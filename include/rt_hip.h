@@ -189,7 +189,8 @@ int rt_tonemap_u8(const float* accum_rgb, int32_t n_pixels, int32_t spp, uint8_t
 /* Writes a binary PPM (P6) of the tonemapped image. */
 int rt_write_ppm(const char* path, const uint8_t* rgb, int32_t width, int32_t height);
 /* out_image.save(output) of src/main.rs:600: the format follows the file extension as in the `image` crate.  Supported here:
- * .png (8-bit RGB, stored deflate) and .ppm; anything else is RT_ERR_UNSUPPORTED. */
+ * .jpeg / .jpg (baseline DCT, 4:4:4, quality 75; ./image.jpeg is the reference's default output, src/main.rs:502), .png (8-bit
+ * RGB, stored deflate) and .ppm; anything else is RT_ERR_UNSUPPORTED. */
 int rt_write_image(const char* path, const uint8_t* rgb, int32_t width, int32_t height);
 /* Checkpoints of the accumulation buffer, so that a long render (configs/final_scene.yml asks for 100 000 spp) can stop and
  * resume: the next call renders with sample_offset = spp_done.  The reference has nothing of the kind (src/main.rs:601 saves

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cctype>
+#include <string>
 #include <vector>
 #include "capi_internal.h"
 
@@ -189,6 +190,128 @@ static int write_png(const char* path, const uint8_t* rgb, int32_t w, int32_t h)
     return wr == out.size() ? RT_OK : rt_set_error(RT_ERR_INVALID, "short write");
 }
 
+
+// ---- JPEG (baseline DCT, 8-bit, YCbCr 4:4:4, the example quantisation and Huffman tables of ITU-T T.81 Annex K scaled to
+// quality 75).  The reference saves through the image crate, which picks the encoder by extension and defaults to
+// "./image.jpeg" (main.rs:502, 600).
+namespace {
+struct JpegBits {
+    std::vector<uint8_t>& out; uint32_t acc = 0; int n = 0;
+    explicit JpegBits(std::vector<uint8_t>& o) : out(o) {}
+    void put(uint32_t code, int len) {
+        acc = (acc << len) | (code & ((1u << len) - 1u)); n += len;
+        while (n >= 8) { uint8_t b = (uint8_t)(acc >> (n - 8)); out.push_back(b); if (b == 0xFF) out.push_back(0); n -= 8; }
+    }
+    void flush() { if (n > 0) put(0x7Fu, 8 - n); }
+};
+struct JpegHuff { uint16_t code[256]; uint8_t len[256]; };
+void jpeg_huff(const uint8_t* counts, const uint8_t* symbols, JpegHuff& h) {   // canonical codes from the (BITS, HUFFVAL) lists
+    std::memset(&h, 0, sizeof(h));
+    uint16_t code = 0; int k = 0;
+    for (int l = 1; l <= 16; ++l) { for (int i = 0; i < counts[l - 1]; ++i) { h.code[symbols[k]] = code++; h.len[symbols[k]] = (uint8_t)l; ++k; } code <<= 1; }
+}
+const uint8_t kZig[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                          35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+const uint8_t kQLum[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                           18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+const uint8_t kQChr[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+                           99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+const uint8_t kDcLumN[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0}, kDcChrN[16] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+const uint8_t kDcSym[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+const uint8_t kAcLumN[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d}, kAcChrN[16] = {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+const uint8_t kAcLumSym[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1,
+    0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37,
+    0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a,
+    0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3,
+    0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3,
+    0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+const uint8_t kAcChrSym[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1,
+    0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36,
+    0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69,
+    0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a,
+    0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca,
+    0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+void jpeg_marker(std::vector<uint8_t>& o, uint8_t m, const std::vector<uint8_t>& body) {
+    o.push_back(0xFF); o.push_back(m);
+    o.push_back((uint8_t)((body.size() + 2) >> 8)); o.push_back((uint8_t)((body.size() + 2) & 0xFF));
+    o.insert(o.end(), body.begin(), body.end());
+}
+void jpeg_fdct(float* b) {   // separable 8x8 DCT-II, orthonormal scaling (the 1/4 C(u) C(v) of T.81 A.3.3)
+    static float c[8][8]; static bool init = false;
+    if (!init) { for (int u = 0; u < 8; ++u) for (int x = 0; x < 8; ++x) c[u][x] = (u ? 0.5f : 0.35355339f) * std::cos((2 * x + 1) * u * 3.14159265358979f / 16.0f); init = true; }
+    float t[64];
+    for (int y = 0; y < 8; ++y) for (int u = 0; u < 8; ++u) { float s = 0; for (int x = 0; x < 8; ++x) s += c[u][x] * b[y * 8 + x]; t[y * 8 + u] = s; }
+    for (int u = 0; u < 8; ++u) for (int v = 0; v < 8; ++v) { float s = 0; for (int y = 0; y < 8; ++y) s += c[v][y] * t[y * 8 + u]; b[v * 8 + u] = s; }
+}
+int jpeg_bits_of(int v) { int a = v < 0 ? -v : v, n = 0; while (a) { ++n; a >>= 1; } return n; }
+void jpeg_block(JpegBits& bw, const float* px, const uint8_t* q, const JpegHuff& dc, const JpegHuff& ac, int& pred) {
+    float b[64];
+    for (int i = 0; i < 64; ++i) b[i] = px[i] - 128.0f;
+    jpeg_fdct(b);
+    int z[64];
+    for (int i = 0; i < 64; ++i) z[i] = (int)std::lround(b[kZig[i]] / (float)q[kZig[i]]);
+    int diff = z[0] - pred; pred = z[0];
+    int n = jpeg_bits_of(diff);
+    bw.put(dc.code[n], dc.len[n]);
+    if (n) bw.put((uint32_t)(diff < 0 ? diff - 1 : diff), n);
+    int run = 0;
+    for (int i = 1; i < 64; ++i) {
+        if (z[i] == 0) { ++run; continue; }
+        while (run > 15) { bw.put(ac.code[0xF0], ac.len[0xF0]); run -= 16; }
+        int s = jpeg_bits_of(z[i]);
+        bw.put(ac.code[(run << 4) | s], ac.len[(run << 4) | s]);
+        bw.put((uint32_t)(z[i] < 0 ? z[i] - 1 : z[i]), s);
+        run = 0;
+    }
+    if (run) bw.put(ac.code[0], ac.len[0]);
+}
+}  // namespace
+static int write_jpeg(const char* path, const uint8_t* rgb, int32_t w, int32_t h) {
+    if (w > 65535 || h > 65535) return rt_set_error(RT_ERR_INVALID, "JPEG holds at most 65535 x 65535 pixels");
+    const int quality = 75, scale = 200 - 2 * quality;   // the usual scaling of the Annex K tables
+    uint8_t ql[64], qc[64];
+    for (int i = 0; i < 64; ++i) {
+        ql[i] = (uint8_t)std::min(255, std::max(1, (kQLum[i] * scale + 50) / 100));
+        qc[i] = (uint8_t)std::min(255, std::max(1, (kQChr[i] * scale + 50) / 100));
+    }
+    std::vector<uint8_t> o = {0xFF, 0xD8};
+    jpeg_marker(o, 0xE0, {'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0});
+    for (int t = 0; t < 2; ++t) { std::vector<uint8_t> b = {(uint8_t)t}; for (int i = 0; i < 64; ++i) b.push_back((t ? qc : ql)[kZig[i]]); jpeg_marker(o, 0xDB, b); }
+    jpeg_marker(o, 0xC0, {8, (uint8_t)(h >> 8), (uint8_t)(h & 0xFF), (uint8_t)(w >> 8), (uint8_t)(w & 0xFF), 3, 1, 0x11, 0, 2, 0x11, 1, 3, 0x11, 1});
+    struct { uint8_t id; const uint8_t* n; const uint8_t* sym; int count; } tabs[4] = {
+        {0x00, kDcLumN, kDcSym, 12}, {0x10, kAcLumN, kAcLumSym, 162}, {0x01, kDcChrN, kDcSym, 12}, {0x11, kAcChrN, kAcChrSym, 162}};
+    for (auto& t : tabs) { std::vector<uint8_t> b = {t.id}; b.insert(b.end(), t.n, t.n + 16); b.insert(b.end(), t.sym, t.sym + t.count); jpeg_marker(o, 0xC4, b); }
+    jpeg_marker(o, 0xDA, {3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0});
+    JpegHuff dcl, acl, dcc, acc;
+    jpeg_huff(kDcLumN, kDcSym, dcl); jpeg_huff(kAcLumN, kAcLumSym, acl); jpeg_huff(kDcChrN, kDcSym, dcc); jpeg_huff(kAcChrN, kAcChrSym, acc);
+    JpegBits bw(o);
+    int pred[3] = {0, 0, 0};
+    for (int by = 0; by < h; by += 8)
+        for (int bx = 0; bx < w; bx += 8) {
+            float ycc[3][64];
+            for (int y = 0; y < 8; ++y)
+                for (int x = 0; x < 8; ++x) {   // edge blocks repeat the last row / column
+                    const uint8_t* p = rgb + 3 * ((size_t)std::min(by + y, h - 1) * w + std::min(bx + x, w - 1));
+                    float r = p[0], g = p[1], b = p[2];
+                    ycc[0][y * 8 + x] = 0.299f * r + 0.587f * g + 0.114f * b;
+                    ycc[1][y * 8 + x] = -0.168736f * r - 0.331264f * g + 0.5f * b + 128.0f;
+                    ycc[2][y * 8 + x] = 0.5f * r - 0.418688f * g - 0.081312f * b + 128.0f;
+                }
+            jpeg_block(bw, ycc[0], ql, dcl, acl, pred[0]);
+            jpeg_block(bw, ycc[1], qc, dcc, acc, pred[1]);
+            jpeg_block(bw, ycc[2], qc, dcc, acc, pred[2]);
+        }
+    bw.flush();
+    o.push_back(0xFF); o.push_back(0xD9);
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return rt_set_error(RT_ERR_INVALID, std::string("cannot open ") + path);
+    bool ok = std::fwrite(o.data(), 1, o.size(), f) == o.size();
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? RT_OK : rt_set_error(RT_ERR_INVALID, std::string("cannot write ") + path);
+}
+
 int rt_write_image(const char* path, const uint8_t* rgb, int32_t w, int32_t h) {
     if (!path || !rgb || w <= 0 || h <= 0) return rt_set_error(RT_ERR_INVALID, "bad argument");
     std::string p(path);
@@ -197,7 +320,8 @@ int rt_write_image(const char* path, const uint8_t* rgb, int32_t w, int32_t h) {
     for (char& c : ext) c = (char)std::tolower((unsigned char)c);
     if (ext == "png") return write_png(path, rgb, w, h);
     if (ext == "ppm" || ext == "pnm") return rt_write_ppm(path, rgb, w, h);
-    return rt_set_error(RT_ERR_UNSUPPORTED, "image format '" + ext + "' is not supported (png, ppm)");
+    if (ext == "jpg" || ext == "jpeg") return write_jpeg(path, rgb, w, h);
+    return rt_set_error(RT_ERR_UNSUPPORTED, "image format '" + ext + "' is not supported (png, jpeg, ppm)");
 }
 
 // ---- accumulator checkpoints: header {magic, width, height, spp_done, seed} then width * height * 3 floats

@@ -1,5 +1,5 @@
 // rt_cli.cpp -- command-line driver with the flags of the reference binary (main.rs:496-504):
-//   rt_cli -c <config.yml> [-o <image.png|.ppm>]  plus  --spp N  --seed N  --scene-seed N  --device N  --background r,g,b
+//   rt_cli -c <config.yml> [-o <image.jpeg|.png|.ppm>]   (default ./image.jpeg, main.rs:502)  plus  --spp N  --seed N  --scene-seed N  --device N  --background r,g,b
 //                                                       --checkpoint <file>  --pass-spp N
 // It does what main() does (main.rs:506-601) with the render loop replaced by rt_render: read the
 // config, build the scene, render samples_per_pixel samples, tonemap (utils.rs:49-63), save.
@@ -19,7 +19,7 @@
 static int die(const char* what) { std::fprintf(stderr, "rt_cli: %s: %s\n", what, rt_last_error()); return 1; }
 
 int main(int argc, char** argv) {
-    std::string config, output = "./image.ppm", checkpoint;
+    std::string config, output = "./image.jpeg", checkpoint;
     long long pass_spp = 1024;
     long long spp_override = -1; unsigned long long seed = 0x5EED0002ull, scene_seed = 0x5EED0001ull; int device = 0;
     float bg[3] = {0, 0, 0}; bool bg_given = false;
@@ -35,7 +35,7 @@ int main(int argc, char** argv) {
         else if (a == "--checkpoint") checkpoint = next("--checkpoint");
         else if (a == "--pass-spp") pass_spp = std::max(1LL, std::atoll(next("--pass-spp")));
         else if (a == "--background") { if (std::sscanf(next("--background"), "%f,%f,%f", &bg[0], &bg[1], &bg[2]) != 3) { std::fprintf(stderr, "rt_cli: --background r,g,b\n"); return 2; } bg_given = true; }
-        else { std::fprintf(stderr, "usage: rt_cli -c <config.yml> [-o <image.ppm>] [--spp N] [--seed N] [--scene-seed N] [--device N] [--background r,g,b] [--checkpoint <file>] [--pass-spp N]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: rt_cli -c <config.yml> [-o <image.jpeg|.png|.ppm>] [--spp N] [--seed N] [--scene-seed N] [--device N] [--background r,g,b] [--checkpoint <file>] [--pass-spp N]\n"); return 2; }
     }
     if (config.empty()) { std::fprintf(stderr, "rt_cli: the following required arguments were not provided: --config <CONFIG>\n"); return 2; }
 

@@ -178,6 +178,25 @@ def test_tonemap_matches_utils_rs():  # utils.rs:49-63
     assert rgb.tolist() == [[128, 255, 0], [255, 0, int(256 * np.sqrt(0.5))]]
 
 
+def test_jpeg_writer_decodes_to_the_image(tmp_path):
+    """The reference saves to ./image.jpeg by default (main.rs:502, 600).  The baseline JPEG rt_write_image produces must decode
+    (with an independent decoder) to the same picture within quantisation error, at sizes that are no multiple of 8 too."""
+    Image = pytest.importorskip("PIL.Image")
+    for w, h in [(64, 48), (37, 29), (1, 1), (8, 8)]:
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = np.stack([xx * 255 // max(w - 1, 1), yy * 255 // max(h - 1, 1), (xx + yy) * 255 // max(w + h - 2, 1)], -1).astype(np.uint8)
+        path = str(tmp_path / ("a%dx%d.jpeg" % (w, h)))
+        rt.write_image(path, img)
+        raw = open(path, "rb").read()
+        assert raw[:2] == b"\xff\xd8" and raw[-2:] == b"\xff\xd9"
+        got = np.asarray(Image.open(path).convert("RGB")).astype(int)
+        assert got.shape == (h, w, 3)
+        err = np.abs(got - img.astype(int))
+        assert err.mean() < 3.0 and err.max() < 40, (w, h, err.mean(), err.max())
+    with pytest.raises(rt.RtError):
+        rt.write_image(str(tmp_path / "a.bmp"), np.zeros((4, 4, 3), np.uint8))
+
+
 def test_png_and_ppm_writers_and_checkpoints(tmp_path):
     """rt_write_image follows the extension (main.rs:600); the PNG is decoded here with zlib.  Accumulator checkpoints round-trip."""
     import struct
@@ -203,7 +222,7 @@ def test_png_and_ppm_writers_and_checkpoints(tmp_path):
     rt.write_image(ppm, rgb)
     assert open(ppm, "rb").read() == b"P6\n53 37\n255\n" + rgb.tobytes()
     with pytest.raises(rt.RtError) as e:
-        rt.write_image(str(tmp_path / "a.jpg"), rgb)
+        rt.write_image(str(tmp_path / "a.tiff"), rgb)
     assert e.value.code == -6
     acc = rng.random((37, 53, 3), dtype=np.float32) * 100
     ck = str(tmp_path / "acc.bin")
