@@ -643,6 +643,8 @@ struct RtScene {
     int shade_lds_bytes = 0;
 };
 
+static const int kLdsBudget = 160 * 1024 - 512;   // dynamic LDS a 1024-thread block may ask for (one block per CU)
+
 // k_trace comes in two block shapes: 1024 threads (one block per CU; its 16 waves share one LDS copy of the scene) and,
 // where a workgroup cannot have that much LDS, 256 threads (four blocks per CU, each with a 40 KB plan).
 static void launch_trace(RtScene* s, bool stats, hipStream_t st, uint32_t cap, const uint32_t* cin, uint32_t* cursors,
@@ -708,14 +710,16 @@ static int plan_trace(RtScene* s) {
     const char* env_w = std::getenv("RT_TRACE_WIDE_STACK"); const bool narrow_ok = !(env_w && std::atoi(env_w) != 0);
     int blocks_per_cu = 1;
     bool planned = false;
-    if (want == 1024 && s->flat.max_stack * 1024 * 4 + 64 <= 160 * 1024 - 512) {
-        fill_plan(s->view, s->flat.max_stack, 1024, 160 * 1024 - 512, refill, narrow_ok, s->top_first, s->plan, s->lds_bytes);
+    if (want == 1024 && s->flat.max_stack * 1024 * 4 + 64 <= kLdsBudget) {
+        fill_plan(s->view, s->flat.max_stack, 1024, kLdsBudget, refill, narrow_ok, s->top_first, s->plan, s->lds_bytes);
         const void* fns[2];
         if (s->plan.resident) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, false, true>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, false, true>); }
         else if (!s->plan.wide_stack) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, false, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, false, false>); }
         else { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, false>); }
-        hipError_t e = hipFuncSetAttribute(fns[0], hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
-        if (e == hipSuccess) e = hipFuncSetAttribute(fns[1], hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes);
+        // the limit is a property of the kernel, not of this scene: always the whole budget, so that a scene created
+        // later with a smaller plan does not lower it for this one
+        hipError_t e = hipFuncSetAttribute(fns[0], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
+        if (e == hipSuccess) e = hipFuncSetAttribute(fns[1], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
         if (e == hipSuccess) { s->trace_block = 1024; planned = true; }
         else (void)hipGetLastError();   // this device does not give one workgroup that much LDS: use the small blocks
     }
@@ -753,8 +757,8 @@ static int plan_shade(RtScene* s) {
     place((long)v.n_media * RT_MEDIUM_F4, pl.off_media);
     place((long)v.n_perlin * RT_PERLIN_VEC_F4, pl.off_perlin_vec);
     place((long)v.n_perlin * (RT_PERLIN_PERM_BYTES / 16), pl.off_perlin_perm);
-    if (used * 16 > 160 * 1024 - 512 || s->n_cu < RT_SHARDS) return RT_OK;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade_lds), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(used * 16)) != hipSuccess) {
+    if (used * 16 > kLdsBudget || s->n_cu < RT_SHARDS) return RT_OK;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade_lds), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget) != hipSuccess) {
         (void)hipGetLastError();   // this device does not give one workgroup that much LDS
         return RT_OK;
     }

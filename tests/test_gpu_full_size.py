@@ -170,6 +170,23 @@ def test_shading_kernels_agree_on_ragged_sizes(gpu_required, size):
     assert np.array_equal(images[0][0], images[1][0]) and np.array_equal(images[0][1], images[1][1])
 
 
+def test_scenes_with_different_lds_plans_coexist(gpu_required):
+    """The kernels' dynamic-LDS limit is set once per kernel, not per scene: a scene with a large LDS plan must still render
+    after a scene with a small one has been created (and the other way round)."""
+    def make(name):
+        cfg, cam = config_camera(name)
+        b = rt.Builder()
+        return rt.Scene(b, b.scene_from_config(os.path.join(CONFIGS, name), SCENE_SEED), 0), cam, rt.render_params(96, 96, 2, cfg.max_depth, RENDER_SEED)
+    big, cam_b, p_b = make("final_scene.yml")
+    want_b, _, _ = big.render(cam_b, p_b)
+    small, cam_s, p_s = make("rectangle.yml")
+    want_s, _, _ = small.render(cam_s, p_s)
+    got_b, _, _ = big.render(cam_b, p_b)
+    got_s, _, _ = small.render(cam_s, p_s)
+    assert np.array_equal(got_b, want_b) and np.array_equal(got_s, want_s)
+    big.close(); small.close()
+
+
 def test_cli_checkpoint_and_resume(gpu_required, tmp_path):
     """rt_cli renders in passes with --checkpoint, continues an existing checkpoint, and writes PNG by extension."""
     import subprocess
