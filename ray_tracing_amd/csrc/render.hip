@@ -55,7 +55,7 @@ struct LdsStack {  // one column of the block's LDS stack: entry i of thread t l
 };
 
 __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev fr, uint32_t n_paths, uint32_t cap, uint32_t* counts1,
-                                                     rt_f4* qa, rt_f4* qb, rt_f4* qc) {
+                                                     rt_f4* qa, rt_f4* qb, rt_f4* qc, rt_f4* contrib) {
     // Chunks of 256 consecutive path ids are dealt round-robin to the regions.
     if (blockIdx.x == 0 && threadIdx.x < RT_SHARDS) {
         uint32_t n_chunks = (n_paths + RT_BLOCK - 1) / RT_BLOCK, sh = threadIdx.x;
@@ -78,6 +78,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev
         *reinterpret_cast<float4*>(qa + slot) = make_float4(a.x, a.y, a.z, a.w);
         *reinterpret_cast<float4*>(qb + slot) = make_float4(b.x, b.y, b.z, b.w);
         *reinterpret_cast<float4*>(qc + slot) = make_float4(c.x, c.y, c.z, c.w);
+        *reinterpret_cast<float4*>(contrib + pid) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // the path's light, written where it ends (k_shade)
     }
 }
 
@@ -1035,9 +1036,8 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
         fr.spp_chunk = chunk; fr.sample_base = p->sample_offset + done;
         HIP_TRY(hipMemsetAsync(s->counts, 0, counts_bytes, st));
         HIP_TRY(hipMemsetAsync(s->counts + (size_t)(RT_MAX_BOUNCES + 2) * RT_SHARDS * RT_COUNT_STRIDE, 0, counts_bytes, st));
-        HIP_TRY(hipMemsetAsync(s->contrib, 0, (size_t)n_paths * sizeof(rt_f4), st));
         int grid = (int)std::min<size_t>(((size_t)n_paths + RT_BLOCK - 1) / RT_BLOCK, (size_t)grid_cap);
-        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, cd, fr, n_paths, cap, s->counts + RT_SHARDS * RT_COUNT_STRIDE, s->qa[0], s->qb[0], s->qc[0]);
+        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, cd, fr, n_paths, cap, s->counts + RT_SHARDS * RT_COUNT_STRIDE, s->qa[0], s->qb[0], s->qc[0], s->contrib);
         // bounce grid: x = blocks per region (a multiple of RT_SHARDS, see the capacity argument above), y = region
         int gx = (int)std::min<size_t>(((size_t)n_paths / RT_SHARDS + RT_BLOCK - 1) / RT_BLOCK + 1, (size_t)grid_cap / RT_SHARDS);
         gx = std::max(RT_SHARDS, (gx + RT_SHARDS - 1) / RT_SHARDS * RT_SHARDS);
