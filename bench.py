@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="final_scene.yml", choices=["final_scene.yml", "cornell.yml"])
-    ap.add_argument("--spp-per-step", type=int, default=256)
+    ap.add_argument("--spp-per-step", type=int, default=400)
     ap.add_argument("--cpu-spp", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the second config of the metric (cornell.yml / final_scene.yml)")

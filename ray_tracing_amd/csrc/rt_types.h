@@ -26,7 +26,9 @@ enum { RT_KIND_SPHERE = 0, RT_KIND_MSPHERE = 1, RT_KIND_RECT = 2, RT_KIND_BOX = 
 //   else       : kind = (x >> 28) & 3, count = ((x >> 26) & 3) + 1, first = x & 0x03FFFFFF
 // An absent child has an empty box (min = +inf, max = -inf) and is never entered.
 #define RT_LEAF_INSTANCE_BIT 0x40000000
+#ifndef RT_LEAF_MAX_PRIMS
 #define RT_LEAF_MAX_PRIMS 4
+#endif
 static inline int32_t rt_leaf_prims(int kind, int first, int count) {
     return ~(int32_t)(((uint32_t)kind << 28) | ((uint32_t)(count - 1) << 26) | (uint32_t)first);
 }
