@@ -429,6 +429,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev f
 struct RtShadePlan {
     int32_t off_spheres, off_sphere_meta, off_mspheres, off_msphere_meta, off_rects, off_rect_meta, off_boxes, off_instances, off_ops,
             off_materials, off_textures, off_media, off_perlin_vec, off_perlin_perm, off_stage, off_later;
+    int32_t off_nodes, off_stack, stack_cap;   // FUSED only: the whole node array and a traversal stack of 32-bit entries per lane
 };
 typedef int __attribute__((ext_vector_type(2))) rt_vi2;
 typedef __attribute__((address_space(3))) const rt_vi2 lds_i2;
@@ -455,6 +456,10 @@ struct ShadeTables {   // every table from the block's LDS copy
     __device__ __forceinline__ rt_f4 get(int m, int k) const { return medium(m, k); }   // as a MediaSrc
     __device__ __forceinline__ rt_f4 perlin_vec(int table, int h) const { return lds_ld4(lds + pl.off_perlin_vec + table * RT_PERLIN_VEC_F4 + h); }
     __device__ __forceinline__ int perlin_perm(int table, int i) const { return ((lds_u8*)(lds + pl.off_perlin_perm))[table * RT_PERLIN_PERM_BYTES + i]; }
+    __device__ __forceinline__ void get(int32_t n, rt_f4 q[4]) const {   // as a Nodes source (FUSED)
+        lds_f4* p = lds + pl.off_nodes + 4 * n;
+        q[0] = lds_ld4(p); q[1] = lds_ld4(p + 1); q[2] = lds_ld4(p + 2); q[3] = lds_ld4(p + 3);
+    }
 };
 
 // The ray and hit records of 64 consecutive queue entries, copied by the memory pipeline straight into the wave's staging
@@ -466,17 +471,21 @@ __device__ __forceinline__ void shade_stage_one(const rt_f4* src, lds_f4* dst) {
     uint32_t m0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)dst);
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0), "v"(src) : "memory");
 }
+template <bool NO_HITS>
 __device__ __forceinline__ void shade_stage(const rt_f4* ia, const rt_f4* ib, const rt_f4* ic, const rt_f4* hits, uint32_t i, lds_f4* stage) {
     shade_stage_one(ia + i, stage);
     shade_stage_one(ib + i, stage + 64);
     shade_stage_one(ic + i, stage + 128);
-    shade_stage_one(hits + i, stage + 192);
+    if (!NO_HITS) shade_stage_one(hits + i, stage + 192);
 }
 
 // The same stage for scenes whose shading tables fit one CU's LDS: one 1024-thread block per CU copies them once; the
 // common path of a ray then has no dependent global-memory fetch at all, and the next 64 records of every wave travel
 // into LDS while the current ones are shaded.  The wave waits for them at the top of the next iteration, which costs
 // nothing when an append happened in between (it waited for all earlier memory operations already).
+// FUSED (scenes of a handful of nodes): the closest hit is found here too, by the plain per-ray traversal over the node
+// array in LDS, and no closest-hit kernel runs: the hit record never exists in memory and the ray record is read once.
+template <bool FUSED>
 __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan pl, RtFrameDev fr, int bounce, uint32_t cap, const uint32_t* counts_in,
                                                     uint32_t* counts_out, const rt_f4* ia, const rt_f4* ib, const rt_f4* ic,
                                                     const rt_f4* hits, rt_f4* oa, rt_f4* ob, rt_f4* oc, rt_f4* contrib) {
@@ -497,6 +506,7 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
         for (int i = t; i < sc.n_media * RT_MEDIUM_F4; i += 1024) dst[pl.off_media + i] = ld4(sc.media + i);
         for (int i = t; i < sc.n_perlin * RT_PERLIN_VEC_F4; i += 1024) dst[pl.off_perlin_vec + i] = ld4(sc.perlin_vec + i);
         for (int i = t; i < sc.n_perlin * (RT_PERLIN_PERM_BYTES / 16); i += 1024) dst[pl.off_perlin_perm + i] = ld4(reinterpret_cast<const rt_f4*>(sc.perlin_perm) + i);
+        if (FUSED) for (int i = t; i < sc.n_nodes * 4; i += 1024) dst[pl.off_nodes + i] = ld4(sc.nodes + i);
         rt_i2* m;
         m = reinterpret_cast<rt_i2*>(dst + pl.off_sphere_meta); for (int i = t; i < sc.n_spheres; i += 1024) m[i] = sc.sphere_meta[i];
         m = reinterpret_cast<rt_i2*>(dst + pl.off_msphere_meta); for (int i = t; i < sc.n_mspheres; i += 1024) m[i] = sc.msphere_meta[i];
@@ -516,16 +526,29 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
     const uint32_t stride = gridDim.x * 1024u;
     uint32_t n_later = 0;                                              // wave-uniform
     uint32_t base = blockIdx.x * 1024u + wave * 64u;                   // wave-uniform
-    if (base < n) shade_stage(ia, ib, ic, hits, min(base + lane, n - 1u), stage);
+    TraceStack<true> stk;   // FUSED
+    stk.base = (lds_int*)(tab.lds + pl.off_stack) + threadIdx.x; stk.depth = pl.stack_cap; stk.stride = 1024;
+    // the closest hit of ray (a, b) as the record k_trace would have written
+    auto closest = [&](rt_f4 a, rt_f4 b) -> rt_f4 {
+        RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
+        rt_closest_hit_in<false>(sc, tab, tab, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, RT_TMIN, (uint32_t)f2i(b.w), stk, hit, nullptr);
+        rt_f4 h; h.x = hit.t; h.y = i2f((int)hit.code); h.z = i2f(hit.inst); h.w = 0.0f;
+        return h;
+    };
+    if (base < n) shade_stage<FUSED>(ia, ib, ic, hits, min(base + lane, n - 1u), stage);
     bool landed = false;                                               // the staged records are known to have arrived
     for (; base < n; base += stride) {
         const uint32_t i = base + lane;
         if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        rt_f4 a = lds_ld4(stage + lane), b = lds_ld4(stage + 64 + lane), c = lds_ld4(stage + 128 + lane), h = lds_ld4(stage + 192 + lane);
+        rt_f4 a = lds_ld4(stage + lane), b = lds_ld4(stage + 64 + lane), c = lds_ld4(stage + 128 + lane), h;
+        if (!FUSED) h = lds_ld4(stage + 192 + lane);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the records are in registers, the staging area is free
-        if (base + stride < n) shade_stage(ia, ib, ic, hits, min(i + stride, n - 1u), stage);
+        if (base + stride < n) shade_stage<FUSED>(ia, ib, ic, hits, min(i + stride, n - 1u), stage);
         ShadeOut out; shade_out_clear(out);
-        if (i < n) shade_ray<false>(sc, tab, tab, fr, bounce, a, b, c, h, may_postpone, contrib, nullptr, out);
+        if (i < n) {
+            if (FUSED) h = closest(a, b);
+            shade_ray<false>(sc, tab, tab, fr, bounce, a, b, c, h, may_postpone, contrib, nullptr, out);
+        }
         landed = shade_append(out, n_out_ptr, cap, oa, ob, oc);
         unsigned long long pm = __ballot(out.postponed);
         if (pm) {
@@ -537,7 +560,8 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
                 __builtin_amdgcn_wave_barrier();
                 uint32_t j = later[n_later + lane];
                 ShadeOut o2; shade_out_clear(o2);
-                shade_ray<false>(sc, tab, tab, fr, bounce, ld4(ia + j), ld4(ib + j), ld4(ic + j), ld4(hits + j), false, contrib, nullptr, o2);
+                { rt_f4 a2 = ld4(ia + j), b2 = ld4(ib + j);
+                  shade_ray<false>(sc, tab, tab, fr, bounce, a2, b2, ld4(ic + j), FUSED ? closest(a2, b2) : ld4(hits + j), false, contrib, nullptr, o2); }
                 shade_append(o2, n_out_ptr, cap, oa, ob, oc);
                 landed = true;                                         // those loads were issued after the staging and have returned
             }
@@ -547,7 +571,10 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
         __builtin_amdgcn_wave_barrier();
         uint32_t j = lane < n_later ? later[lane] : 0u;
         ShadeOut o2; shade_out_clear(o2);
-        if (lane < n_later) shade_ray<false>(sc, tab, tab, fr, bounce, ld4(ia + j), ld4(ib + j), ld4(ic + j), ld4(hits + j), false, contrib, nullptr, o2);
+        if (lane < n_later) {
+            rt_f4 a2 = ld4(ia + j), b2 = ld4(ib + j);
+            shade_ray<false>(sc, tab, tab, fr, bounce, a2, b2, ld4(ic + j), FUSED ? closest(a2, b2) : ld4(hits + j), false, contrib, nullptr, o2);
+        }
         shade_append(o2, n_out_ptr, cap, oa, ob, oc);
     }
 }
@@ -640,6 +667,7 @@ struct RtScene {
     int top_first = 0;                     // first node of the region k_trace should keep in LDS (see plan_trace)
     int trace_block = 1024;                // threads per k_trace block (1024, or 256 where a block cannot have 160 KB of LDS)
     bool shade_lds = false;                // the shading tables fit one CU's LDS: k_shade_lds instead of k_shade
+    bool shade_fused = false;              // ... and the BVH is a handful of nodes: k_shade_lds<true> finds the closest hits too, k_trace is not run
     RtShadePlan shade_plan;                // k_shade_lds: layout of the block's LDS
     int shade_lds_bytes = 0;
 };
@@ -739,7 +767,7 @@ static int plan_trace(RtScene* s) {
 // Decides whether the scene's shading tables, 4 KB of ray staging per wave and the lists of postponed hits fit the LDS of
 // one CU; then k_shade_lds replaces k_shade.
 static int plan_shade(RtScene* s) {
-    s->shade_lds = false;
+    s->shade_lds = false; s->shade_fused = false;
     if (const char* e = std::getenv("RT_SHADE_LDS")) { if (std::atoi(e) == 0) return RT_OK; }
     const RtSceneView& v = s->view;
     RtShadePlan& pl = s->shade_plan;
@@ -759,11 +787,23 @@ static int plan_shade(RtScene* s) {
     place((long)v.n_perlin * RT_PERLIN_VEC_F4, pl.off_perlin_vec);
     place((long)v.n_perlin * (RT_PERLIN_PERM_BYTES / 16), pl.off_perlin_perm);
     if (used * 16 > kLdsBudget || s->n_cu < RT_SHARDS) return RT_OK;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade_lds), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget) != hipSuccess) {
         (void)hipGetLastError();   // this device does not give one workgroup that much LDS
         return RT_OK;
     }
-    s->shade_lds = true; s->shade_lds_bytes = (int)(used * 16);
+    s->shade_lds = true;
+    // A scene of a few nodes and no instances: its traversal is a few steps per ray, cheaper than a second kernel and a hit
+    // record per ray (cornell.yml +22 %, orig_img.yml +23 %; with instanced boxes in the tree it measured 6 % slower).
+    pl.off_nodes = pl.off_stack = 0; pl.stack_cap = 0;
+    const char* ef = std::getenv("RT_SHADE_FUSED");
+    if (!(ef && std::atoi(ef) == 0) && v.n_nodes >= 1 && v.n_nodes <= 16 && s->flat.max_stack <= 8 && s->flat.blas_depth == 0) {
+        long with = used;
+        int32_t on = (int32_t)with; with += (long)v.n_nodes * 4;
+        int32_t os = (int32_t)with; with += (long)std::max(1, s->flat.max_stack) * 1024 / 4;
+        if (with * 16 <= kLdsBudget) { pl.off_nodes = on; pl.off_stack = os; pl.stack_cap = std::max(1, s->flat.max_stack); used = with; s->shade_fused = true; }
+    }
+    s->shade_lds_bytes = (int)(used * 16);
     return RT_OK;
 }
 
@@ -1052,13 +1092,17 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
             uint32_t* cout = s->counts + (size_t)(b + 1) * RT_SHARDS * RT_COUNT_STRIDE;
             uint32_t* cursors = s->counts + (size_t)(RT_MAX_BOUNCES + 2 + b) * RT_SHARDS * RT_COUNT_STRIDE;
             if (time_trace) HIP_TRY(hipEventRecord(s->ev_trace[2 * (b - 1)], st));
-            launch_trace(s, instrumented, st, cap, cin, cursors, s->qa[in], s->qb[in]);
+            const bool fused = s->shade_fused && !instrumented;
+            if (!fused) launch_trace(s, instrumented, st, cap, cin, cursors, s->qa[in], s->qb[in]);
             if (time_trace) HIP_TRY(hipEventRecord(s->ev_trace[2 * (b - 1) + 1], st));
             if (instrumented)
                 hipLaunchKernelGGL(k_shade<true>, bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, cin, cout, s->qa[in], s->qb[in], s->qc[in], s->hits,
                                    s->qa[outq], s->qb[outq], s->qc[outq], s->contrib, s->work);
+            else if (fused)
+                hipLaunchKernelGGL(k_shade_lds<true>, lgrid, dim3(1024), (size_t)s->shade_lds_bytes, st, s->view, s->shade_plan, fr, b, cap, cin, cout,
+                                   s->qa[in], s->qb[in], s->qc[in], s->hits, s->qa[outq], s->qb[outq], s->qc[outq], s->contrib);
             else if (s->shade_lds)
-                hipLaunchKernelGGL(k_shade_lds, lgrid, dim3(1024), (size_t)s->shade_lds_bytes, st, s->view, s->shade_plan, fr, b, cap, cin, cout,
+                hipLaunchKernelGGL(k_shade_lds<false>, lgrid, dim3(1024), (size_t)s->shade_lds_bytes, st, s->view, s->shade_plan, fr, b, cap, cin, cout,
                                    s->qa[in], s->qb[in], s->qc[in], s->hits, s->qa[outq], s->qb[outq], s->qc[outq], s->contrib);
             else
                 hipLaunchKernelGGL(k_shade<false>, bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, cin, cout, s->qa[in], s->qb[in], s->qc[in], s->hits,

@@ -431,13 +431,11 @@ RT_HD void rt_leaf_step(const Prims& prims, v3 wo, v3 wd, float time, float tmin
 // Whole traversal of one ray.  On entry hit.t = tmax, hit.code = RT_HIT_NONE.  "while-while" organisation: the
 // lane first descends inner nodes until it holds a leaf, then works on leaves, so that on a 64-wide wave the
 // box-test code and the primitive code are not issued in turn for every step of every lane.
-template <bool STATS, class Stack>
-RT_HD void rt_closest_hit(const RtSceneView& sc, v3 wo, v3 wd, float time, float tmin, uint32_t src, Stack& stk, RtHit& hit,
-                          RtCounters* wc) {
+template <bool STATS, class Nodes, class Prims, class Stack>
+RT_HD void rt_closest_hit_in(const RtSceneView& sc, const Nodes& nodes, const Prims& prims, v3 wo, v3 wd, float time, float tmin, uint32_t src,
+                             Stack& stk, RtHit& hit, RtCounters* wc) {
     RtTrav tv;
     rt_trav_begin(sc, wo, wd, tv);
-    RtGlobalNodes nodes; nodes.nodes = sc.nodes;
-    RtGlobalPrims prims; prims.sc = &sc;
     while (tv.cur != RT_EMPTY_STACK) {
         while (rt_is_inner(tv.cur)) rt_node_step<STATS>(nodes, tv, tmin, hit, stk, wc);
         if (tv.cur >= 0) {
@@ -446,6 +444,13 @@ RT_HD void rt_closest_hit(const RtSceneView& sc, v3 wo, v3 wd, float time, float
         }
         do rt_leaf_step<STATS>(prims, wo, wd, time, tmin, src, tv, hit, stk, wc); while (tv.cur < 0);
     }
+}
+template <bool STATS, class Stack>
+RT_HD void rt_closest_hit(const RtSceneView& sc, v3 wo, v3 wd, float time, float tmin, uint32_t src, Stack& stk, RtHit& hit,
+                          RtCounters* wc) {
+    RtGlobalNodes nodes; nodes.nodes = sc.nodes;
+    RtGlobalPrims prims; prims.sc = &sc;
+    rt_closest_hit_in<STATS>(sc, nodes, prims, wo, wd, time, tmin, src, stk, hit, wc);
 }
 
 // ------------------------------------------------------------------ constant media (mediums.rs:39-87)

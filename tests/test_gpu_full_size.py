@@ -112,8 +112,8 @@ def test_synthetic_sphere_field_matches_oracle(gpu_required):
     scene.close()
 
 
-@pytest.mark.parametrize("env", [{"RT_TRACE_WIDE_STACK": "1"}, {"RT_TRACE_BLOCK": "256"}, {"RT_SHADE_LDS": "0"}])
-@pytest.mark.parametrize("name", ["cornell.yml", "final_scene.yml", "showcase.yml"])
+@pytest.mark.parametrize("env", [{"RT_TRACE_WIDE_STACK": "1"}, {"RT_TRACE_BLOCK": "256"}, {"RT_SHADE_LDS": "0"}, {"RT_SHADE_FUSED": "0"}])
+@pytest.mark.parametrize("name", ["cornell.yml", "final_scene.yml", "showcase.yml", "rectangle.yml", "orig_img.yml", "cornell_box.yml", "two_spheres.yml"])
 def test_kernel_variants_agree(gpu_required, name, env):
     """k_trace picks its block shape, stack form and what lives in LDS per scene, and shading runs either from tables in LDS
     with staged ray records (k_shade_lds) or from global memory (k_shade); every choice must give the very same image."""
