@@ -157,6 +157,9 @@ def main():
         rays0 = main_run["rays0"]
         t_s = main_run["trace_ms"] * 1e-3                           # sum of the k_trace launches of the timed steps
         b_s = main_run["kernel_ms"] * 1e-3                          # raygen-to-last-shade span of the timed steps
+        fused = t_s < 0.05 * b_s                                    # tiny scene: the closest hit is found inside the shading kernel
+        if fused:
+            t_s = b_s                                               # ... which is then the dominant (only) bounce kernel
         n_tr = max(main_run["trace_launches"], 1)
         hbm_bytes = TRACE_BYTES["ray"] + TRACE_BYTES["hit"]        # per ray: the queue record in, the hit record out
         gbs = tr_bytes * rays0 / t_s / 1e9                          # geometry bytes charged even though they are LDS-resident
@@ -179,7 +182,8 @@ def main():
                                    % (args.workload, cfg.image_width, cfg.image_height, cfg.max_depth, args.spp_per_step, SCENE_SEED, RENDER_SEED),
                        "paths_per_step": paths, "rays_per_path": main_run["total_rays"] / args.steps / paths,
                        "parallelism": "sample-sharded x%d, reduce(SUM) to rank 0" % world, "image_mean": main_run["mean"]},
-            "roofline": {"kernel": "k_trace (closest hit of every queued ray: BVH2 traversal + primitive tests)", "bound": "hbm",
+            "roofline": {"kernel": "k_shade_lds<fused> (closest hit + shading in one kernel; k_trace is not run for this scene)" if fused else
+                                   "k_trace (closest hit of every queued ray: BVH2 traversal + primitive tests)", "bound": "hbm",
                          "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_ray": tr_bytes, "rays_per_launch": rays0 / n_tr, "bytes_per_launch": tr_bytes * rays0 / n_tr,
                          "hbm_only": {"bytes_per_ray": hbm_bytes, "achieved": gbs_hbm, "frac": gbs_hbm / HBM_PEAK_GBS},
