@@ -28,6 +28,7 @@ from ray_tracing_amd.distributed import reduce_accumulators  # noqa: E402
 SCENE_SEED, RENDER_SEED = 0x5EED0001, 0x5EED0002
 HBM_PEAK_GBS = 8000.0        # HBM3E spec peak
 VALU_PEAK_TFLOPS = 157.3     # fp32 vector peak (packed FMA)
+LDS_PEAK_GBS = 150000.0      # aggregate ds_read_b64/b128 rate with every CU streaming (256 B/clk/CU)
 
 # Algorithmic work per unit: FLOPs (FMA = 2) and compulsory bytes, charged per counted event.
 FLOPS = dict(node=2 * 24, sphere=26, msphere=35, rect=12, box=30, instance=35, medium=20 + 2 * 26, raygen=45,
@@ -59,10 +60,22 @@ def per_ray_work(st):
     return trace_flops / rays, trace_bytes / rays, flops / rays, byts / rays, counts
 
 
+class StressConfig:
+    """BASELINE config 5: 1 000 000 random spheres at 3840x2160, depth 50 (the deep-BVH traversal stress scene; sky background,
+    since nothing in it emits)."""
+    image_width, image_height, max_depth = 3840, 2160, 50
+    background = (0.7, 0.8, 1.0)
+    scene = "Synthetic:1000000"
+    camera = dict(look_from=(0, 260, 1500), look_at=(0, 60, 0), v_up=(0, 1, 0), vfov=40.0, aspect=16 / 9, aperture=0.1, focus_dist=10.0)
+
+
 def load_workload(name, device):
+    b = rt.Builder()
+    if name == "synthetic1m":
+        cfg = StressConfig()
+        return cfg, rt.make_camera(**cfg.camera), rt.Scene(b, b.canned_scene(cfg.scene, SCENE_SEED), device)
     path = os.path.join(ROOT, "configs", name)
     cfg = rt.load_config(path)
-    b = rt.Builder()
     scene = rt.Scene(b, b.scene_from_config(path, SCENE_SEED), device)
     return cfg, rt.camera_from_config(cfg), scene
 
@@ -73,7 +86,7 @@ def run_steps(scene, cam, cfg, spp, steps, first_step, rank, world, accum, strea
         accum.zero_()
         offset = ((first_step + k) * world + rank) * spp          # disjoint sample ranges across ranks and steps
         p = rt.render_params(cfg.image_width, cfg.image_height, spp, cfg.max_depth, RENDER_SEED, sample_offset=offset,
-                             flags=rt.RT_FLAG_TIME_TRACE)   # HIP event pairs around every k_trace launch, on the render stream
+                             background=tuple(getattr(cfg, "background", (0.0, 0.0, 0.0))), flags=rt.RT_FLAG_TIME_TRACE)   # HIP event pairs around every k_trace launch, on the render stream
         st = scene.render_device(cam, p, accum.data_ptr(), None, stream_ptr)
         reduce_accumulators(accum, 0)
         rays += int(st.rays); kernel_ms += st.kernel_ms_extend; launches += int(st.extend_launches)
@@ -100,11 +113,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="final_scene.yml", choices=["final_scene.yml", "cornell.yml"])
+    ap.add_argument("--workload", default="final_scene.yml", choices=["final_scene.yml", "cornell.yml", "synthetic1m"])
     ap.add_argument("--spp-per-step", type=int, default=400)
     ap.add_argument("--cpu-spp", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the second config of the metric (cornell.yml / final_scene.yml)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other configs of the metric (cornell.yml, the 1M-sphere scene)")
+    ap.add_argument("--stress-spp", type=int, default=32, help="samples per step of the 1M-sphere 3840x2160 run reported under `also`")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,15 +139,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(config_name, steps, warmup):
+    def timed(config_name, steps, warmup, spp=None):
+        spp = spp or args.spp_per_step
         cfg, cam, scene = load_workload(config_name, local_rank)
         accum = torch.zeros((cfg.image_height, cfg.image_width, 3), dtype=torch.float32, device=device)
         stream_ptr = torch.cuda.current_stream().cuda_stream
-        run_steps(scene, cam, cfg, args.spp_per_step, warmup, 0, rank, world, accum, stream_ptr)
+        run_steps(scene, cam, cfg, spp, warmup, 0, rank, world, accum, stream_ptr)
         barrier()
         t0 = time.perf_counter()
-        rays, kernel_ms, launches, trace_ms, trace_launches = run_steps(scene, cam, cfg, args.spp_per_step, steps, warmup, rank, world, accum,
-                                                                        stream_ptr)
+        rays, kernel_ms, launches, trace_ms, trace_launches = run_steps(scene, cam, cfg, spp, steps, warmup, rank, world, accum, stream_ptr)
         barrier()
         dt = time.perf_counter() - t0
         tot = torch.tensor([dt, float(rays)], dtype=torch.float64, device=device)
@@ -143,7 +157,7 @@ def main():
             dt, total_rays = float(mx[0]), float(sm[1])
         else:
             total_rays = float(rays)
-        mean = float(accum.mean()) / (args.spp_per_step * world)    # rank 0: image mean of the last step (sanity only)
+        mean = float(accum.mean()) / (spp * world)                  # rank 0: image mean of the last step (sanity only)
         return dict(cfg=cfg, cam=cam, scene=scene, dt=dt, total_rays=total_rays, rays0=rays, kernel_ms=kernel_ms, launches=launches, trace_ms=trace_ms,
                     trace_launches=trace_launches, mean=mean)
 
@@ -161,19 +175,28 @@ def main():
         if fused:
             t_s = b_s                                               # ... which is then the dominant (only) bounce kernel
         n_tr = max(main_run["trace_launches"], 1)
-        hbm_bytes = TRACE_BYTES["ray"] + TRACE_BYTES["hit"]        # per ray: the queue record in, the hit record out
-        gbs = tr_bytes * rays0 / t_s / 1e9                          # geometry bytes charged even though they are LDS-resident
+        hbm_bytes = TRACE_BYTES["ray"] + TRACE_BYTES["hit"]        # per ray: the queue record in, the hit record out -- what crosses HBM
+        if fused:
+            hbm_bytes = SHADE_BYTES["ray_in"] - 16 + SHADE_BYTES["ray_out"] + SHADE_BYTES["contrib"]   # fused kernel: ray in (no hit record), ray out, contribution
         gbs_hbm = hbm_bytes * rays0 / t_s / 1e9
+        gbs_lds = tr_bytes * rays0 / t_s / 1e9                      # with the node / primitive records charged although they are served from LDS
         tfl = tr_flops * rays0 / t_s / 1e12
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload.replace(".yml", ""))
+        wl = args.workload.replace(".yml", "")
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % wl)
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/traffic_%s.json (%s)" % (wl, tj.get("source", "rocprofv3 FETCH_SIZE / WRITE_SIZE passes, committed"))
         issue = None   # VALU issue figures of the same workload from the committed PMC passes (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, ...)
-        vpath = os.path.join(ROOT, "profiles", "valu_%s.json" % args.workload.replace(".yml", ""))
+        vpath = os.path.join(ROOT, "profiles", "valu_%s.json" % wl)
         if os.path.exists(vpath):
-            issue = json.load(open(vpath)).get("kernels", {}).get("k_trace")
+            vj = json.load(open(vpath))
+            issue = vj.get("kernels", {}).get("k_trace")
+            if issue is not None:
+                issue = dict(issue, measured_in_this_run=False, source="profiles/valu_%s.json <- %s" % (wl, vj.get("source", "committed rocprofv3 --pmc passes")))
         paths = cfg.image_width * cfg.image_height * args.spp_per_step * world
+        kname = ("k_shade_lds<fused> (closest hit + shading in one kernel; k_trace is not run for this scene)" if fused else
+                 "k_trace (closest hit of every queued ray: BVH2 traversal + primitive tests)")
         out = {
             "metric": "Mrays/sec (whole node)", "value": main_run["total_rays"] / main_run["dt"] / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_run["dt"] / args.steps * 1e3,
@@ -182,33 +205,53 @@ def main():
                                    % (args.workload, cfg.image_width, cfg.image_height, cfg.max_depth, args.spp_per_step, SCENE_SEED, RENDER_SEED),
                        "paths_per_step": paths, "rays_per_path": main_run["total_rays"] / args.steps / paths,
                        "parallelism": "sample-sharded x%d, reduce(SUM) to rank 0" % world, "image_mean": main_run["mean"]},
-            "roofline": {"kernel": "k_shade_lds<fused> (closest hit + shading in one kernel; k_trace is not run for this scene)" if fused else
-                                   "k_trace (closest hit of every queued ray: BVH2 traversal + primitive tests)", "bound": "hbm",
-                         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_ray": tr_bytes, "rays_per_launch": rays0 / n_tr, "bytes_per_launch": tr_bytes * rays0 / n_tr,
-                         "hbm_only": {"bytes_per_ray": hbm_bytes, "achieved": gbs_hbm, "frac": gbs_hbm / HBM_PEAK_GBS},
-                         "avg_launch_ms": main_run["trace_ms"] / n_tr, "launches": main_run["trace_launches"],
+            # HBM line of the dominant kernel: the bytes that cross HBM (ray record in, hit record out), measured launch time
+            "roofline": {"kernel": kname, "bound": "hbm", "achieved": gbs_hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_hbm / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "bytes_per_ray": hbm_bytes, "rays_per_launch": rays0 / n_tr, "bytes_per_launch": hbm_bytes * rays0 / n_tr,
+                         "avg_launch_ms": t_s * 1e3 / n_tr, "launches": n_tr,
                          "share_of_bounce_time": t_s / b_s, "mrays_per_s_in_kernel": rays0 / t_s / 1e6,
-                         "note": "bytes_per_ray = 32 B ray record in + 16 B hit record out + 64 B per visited BVH node + the record of every "
-                                 "primitive tested; the node records come from the LDS copy of the <1 MB scene, so frac can exceed 1 on the "
-                                 "HBM line -- hbm_only counts just the ray and hit records, the bytes that must cross HBM.  The kernel is bound "
-                                 "by VALU instruction issue of divergent traversal at partial lane occupancy (the fp32 FLOP rate of "
-                                 "roofline_valu counts live lanes only), not by HBM"},
+                         "note": "HBM is not what binds this kernel: the scene (<1 MB) is served from the block's LDS copy and the kernel is bound by "
+                                 "VALU instruction issue of divergent traversal at partial lane occupancy -- see roofline_valu.  lds_charged "
+                                 "prices the node and primitive records too (64 B per visited node + the record of every primitive tested); those "
+                                 "bytes come from LDS, so that figure is compared with the LDS peak, never with HBM"},
             "roofline_valu": {"kernel": "k_trace", "bound": "valu_fp32", "achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": tfl / VALU_PEAK_TFLOPS, "flops_per_ray": tr_flops, "issue": issue},
+                              "frac": tfl / VALU_PEAK_TFLOPS, "flops_per_ray": tr_flops,
+                              "note": "algorithmic FLOPs of live lanes only (FMA = 2); peak = 256 CUs x 128 lanes x 2 x 2.4 GHz, reachable only with packed fp32",
+                              "issue": issue},
+            "lds_charged": {"bytes_per_ray": tr_bytes, "achieved": gbs_lds, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": gbs_lds / LDS_PEAK_GBS,
+                            "note": "ray + hit records + every node and primitive record read, against the aggregate LDS read rate (ds_read_b128, all CUs)"},
             "bounce_total": {"kernels": "k_trace + k_shade", "ms": main_run["kernel_ms"], "launch_pairs": main_run["launches"],
                              "flops_per_ray": flops_per_ray, "bytes_per_ray": bytes_per_ray,
                              "achieved_gbs": bytes_per_ray * rays0 / b_s / 1e9, "achieved_tflops": flops_per_ray * rays0 / b_s / 1e12},
             "work_per_ray": counts,
         }
     if not args.no_secondary:
-        other = "cornell.yml" if args.workload == "final_scene.yml" else "final_scene.yml"
         main_run["scene"].close()
-        sec = timed(other, max(1, args.steps // 2), 1)
+        also = {}
+        for other in ("cornell.yml", "final_scene.yml", "synthetic1m"):
+            if other == args.workload:
+                continue
+            stress = other == "synthetic1m"
+            k = 2 if stress else max(1, args.steps // 2)
+            sec = timed(other, k, 1, args.stress_spp if stress else None)
+            if rank == 0:
+                c = sec["cfg"]
+                also[other] = {"value": sec["total_rays"] / sec["dt"] / 1e6, "unit": "Mrays/s", "steps": k, "ms_per_step": sec["dt"] / k * 1e3,
+                               "workload": "%s: %dx%d, max_depth %d, %d spp per step per GPU" % (getattr(c, "scene", other), c.image_width, c.image_height,
+                                                                                                  c.max_depth, args.stress_spp if stress else args.spp_per_step),
+                               "image_mean": sec["mean"]}
+                if stress:
+                    n_t = max(sec["trace_launches"], 1)
+                    also[other]["k_trace"] = {"avg_launch_ms": sec["trace_ms"] / n_t, "launches": sec["trace_launches"],
+                                              "share_of_bounce_time": sec["trace_ms"] / max(sec["kernel_ms"], 1e-9),
+                                              "mrays_per_s_in_kernel": sec["rays0"] / max(sec["trace_ms"] * 1e-3, 1e-12) / 1e6}
+                    spath = os.path.join(ROOT, "profiles", "memory_synthetic1m.json")   # L2 / fabric counters of this workload (committed PMC passes)
+                    if os.path.exists(spath):
+                        also[other]["roofline"] = dict(json.load(open(spath)), measured_in_this_run=False, source="profiles/memory_synthetic1m.json")
+            sec["scene"].close()
         if rank == 0:
-            out["also"] = {other: {"value": sec["total_rays"] / sec["dt"] / 1e6, "unit": "Mrays/s", "steps": max(1, args.steps // 2),
-                                   "ms_per_step": sec["dt"] / max(1, args.steps // 2) * 1e3, "image_mean": sec["mean"]}}
-        sec["scene"].close()
+            out["also"] = also
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             threads = min(16, os.cpu_count() or 1)

@@ -32,7 +32,9 @@ typedef enum RtStatus {
     RT_ERR_OOM = -4,
     RT_ERR_NO_BBOX = -5,     /* "No bounding box in bvh constructor", src/bvh.rs:140,152,201 */
     RT_ERR_UNSUPPORTED = -6, /* a tree the flat form cannot express */
-    RT_ERR_CONFIG = -7       /* "Could not open config file." / "Could not read values.", src/main.rs:511-512 */
+    RT_ERR_CONFIG = -7,      /* "Could not open config file." / "Could not read values.", src/main.rs:511-512 */
+    RT_ERR_NCCL = -8,        /* an RCCL call of rt_render_multi failed, or librccl could not be loaded */
+    RT_ERR_INTERNAL = -9     /* an invariant of the library failed (a ray queue overflowed): the output is not to be used */
 } RtStatus;
 
 typedef struct RtBuilder RtBuilder; /* host scene graph under construction */
@@ -171,6 +173,17 @@ typedef struct RtStats {
 int rt_render(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* accum_rgb, float* accum_sq, RtStats* stats);
 int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* d_accum_rgb, float* d_accum_sq,
                      void* hip_stream, RtStats* stats);
+
+/* Multi-GPU render inside one process: the per-pixel sum of src/main.rs:585-589 lifted across GPUs.  scenes[i] is the same world
+ * flattened onto GPU i (one handle per GPU, distinct devices).  The samples [sample_offset, sample_offset + spp) are cut into
+ * n_scenes contiguous ranges (rt_shard_samples); GPU i renders its range into a private accumulator on its own host thread and
+ * stream; one ncclReduce(sum, f32, W*H*3) over RCCL brings them to scenes[0]'s GPU, and the result is ADDED to the host buffers.
+ * The Philox counter carries the absolute sample index, so the image equals a one-GPU render up to fp32 summation order; with
+ * n_scenes = 1 it is bit-identical to rt_render.  librccl is loaded on first use (RT_ERR_NCCL if absent or if a call fails). */
+int rt_render_multi(RtScene* const* scenes, int32_t n_scenes, const RtCamera* cam, const RtRenderParams* p, float* accum_rgb,
+                    float* accum_sq, RtStats* stats);
+/* The sample range of shard `shard` of `n_shards`: contiguous, balanced, first shards take the remainder. */
+int rt_shard_samples(int32_t total_spp, int32_t n_shards, int32_t shard, int32_t* first, int32_t* count);
 
 /* Parity hook: closest hit of sample `sample` of every pixel (camera ray + src/lib.rs:63).
  * object_id = creation-order id of the primitive / medium hit, -1 on a miss; t = +inf on a miss.

@@ -102,6 +102,8 @@ API = {
     "rt_flat_destroy": (None, [_P]),
     "rt_render": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtRenderParams), _P, _P, C.POINTER(RtStats)]),
     "rt_render_device": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtRenderParams), _P, _P, _P, C.POINTER(RtStats)]),
+    "rt_render_multi": (C.c_int, [C.POINTER(_P), C.c_int32, C.POINTER(RtCamera), C.POINTER(RtRenderParams), _P, _P, C.POINTER(RtStats)]),
+    "rt_shard_samples": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rt_trace_primary": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtRenderParams), C.c_int32, _P, _P, _P, _P, _P]),
     "rt_scatter_rays": (C.c_int, [_P, _P, C.c_int32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint64, _P]),
     "rt_tonemap_u8": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
@@ -276,6 +278,38 @@ def render_params(width, height, spp, max_depth, seed, sample_offset=0, backgrou
     return p
 
 
+def _with_flags(params, flags):
+    q = RtRenderParams()
+    C.memmove(C.byref(q), C.byref(params), C.sizeof(RtRenderParams))
+    q.flags = flags
+    return q
+
+
+def shard_samples(total_spp, shard, n_shards):
+    """(first_sample, n_samples) of one shard, from the library's own arithmetic (rt_shard_samples)."""
+    first, count = C.c_int32(0), C.c_int32(0)
+    _check(lib().rt_shard_samples(total_spp, n_shards, shard, C.byref(first), C.byref(count)))
+    return first.value, count.value
+
+
+def render_multi(scenes, cam, params, accum=None, want_sumsq=False):
+    """rt_render_multi: one Scene per GPU (the same world on each), sample ranges sharded across them inside this process,
+    one RCCL reduce to the first scene's GPU.  Returns (accum, sumsq|None, stats) like Scene.render."""
+    h, w = params.height, params.width
+    if accum is None:
+        accum = np.zeros((h, w, 3), dtype=np.float32)
+    assert accum.dtype == np.float32 and accum.flags.c_contiguous and accum.shape == (h, w, 3)
+    sumsq = None
+    if want_sumsq:
+        params = _with_flags(params, params.flags | RT_FLAG_SUMSQ)
+        sumsq = np.zeros((h, w, 3), dtype=np.float32)
+    handles = (_P * len(scenes))(*[s._h for s in scenes])
+    st = RtStats()
+    _check(lib().rt_render_multi(handles, len(scenes), C.byref(cam), C.byref(params), accum.ctypes.data,
+                                 sumsq.ctypes.data if sumsq is not None else None, C.byref(st)))
+    return accum, sumsq, st
+
+
 class Scene:
     """A flattened scene resident on one GPU (rt_scene_create)."""
 
@@ -303,7 +337,7 @@ class Scene:
         assert accum.dtype == np.float32 and accum.flags.c_contiguous and accum.shape == (h, w, 3)
         sumsq = None
         if want_sumsq:
-            params.flags |= RT_FLAG_SUMSQ
+            params = _with_flags(params, params.flags | RT_FLAG_SUMSQ)      # a copy: the caller's params keep their flags
             sumsq = np.zeros((h, w, 3), dtype=np.float32)
         st = RtStats()
         _check(lib().rt_render(self._h, C.byref(cam), C.byref(params), accum.ctypes.data,

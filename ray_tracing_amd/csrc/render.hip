@@ -17,11 +17,16 @@
 // Queue sizes live in device memory (counts[b][s] = rays of region s entering bounce b), so a pass runs
 // without a host round trip; the counts double as the ray-segment statistics.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 #include "capi_internal.h"
 #include "rt_device.h"
@@ -54,7 +59,7 @@ struct LdsStack {  // one column of the block's LDS stack: entry i of thread t l
     __host__ __device__ int cap() const { return depth; }
 };
 
-__global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev fr, uint32_t n_paths, uint32_t cap, uint32_t* counts1,
+__global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev fr, uint32_t n_paths, uint32_t cap, uint32_t* counts1, uint32_t* overflow,
                                                      rt_f4* qa, rt_f4* qb, rt_f4* qc, rt_f4* contrib) {
     // Chunks of 256 consecutive path ids are dealt round-robin to the regions.
     if (blockIdx.x == 0 && threadIdx.x < RT_SHARDS) {
@@ -74,11 +79,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev
         b.x = d.x; b.y = d.y; b.z = d.z; b.w = i2f((int)RT_HIT_NONE);
         c.x = 1.0f; c.y = 1.0f; c.z = 1.0f; c.w = i2f((int)pid);
         uint32_t chunk = pid / RT_BLOCK;
-        size_t slot = (size_t)(chunk % RT_SHARDS) * cap + (size_t)(chunk / RT_SHARDS) * RT_BLOCK + pid % RT_BLOCK;
+        uint32_t in_region = (chunk / RT_SHARDS) * RT_BLOCK + pid % RT_BLOCK;
+        *reinterpret_cast<float4*>(contrib + pid) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // the path's light, written where it ends (k_shade)
+        if (in_region >= cap) { atomicAdd(overflow, 1u); continue; }                       // never with a workspace sized for the pass
+        size_t slot = (size_t)(chunk % RT_SHARDS) * cap + in_region;
         *reinterpret_cast<float4*>(qa + slot) = make_float4(a.x, a.y, a.z, a.w);
         *reinterpret_cast<float4*>(qb + slot) = make_float4(b.x, b.y, b.z, b.w);
         *reinterpret_cast<float4*>(qc + slot) = make_float4(c.x, c.y, c.z, c.w);
-        *reinterpret_cast<float4*>(contrib + pid) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // the path's light, written where it ends (k_shade)
     }
 }
 
@@ -171,7 +178,7 @@ template <bool STATS, int TB, bool WIDE, bool RESIDENT>
 __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, uint32_t cap, const uint32_t* counts_in, uint32_t* cursors,
                                               const rt_f4* ia, const rt_f4* ib, rt_f4* hits, unsigned long long* work) {
     const uint32_t region = blockIdx.y;
-    const uint32_t n = counts_in[region * RT_COUNT_STRIDE];
+    const uint32_t n = min(counts_in[region * RT_COUNT_STRIDE], cap);   // a counter can only exceed cap after an overflow (reported by the append)
     if (n == 0) return;
     extern __shared__ __align__(16) unsigned char smem[];
     {   // scene -> LDS
@@ -349,7 +356,7 @@ __device__ __forceinline__ void shade_out_clear(ShadeOut& out) {
 // Append of the scattered rays of one wave to the output queue: one atomic per wave, slot = base + rank among the live
 // lanes (ballot + mbcnt).  Wave-uniform control flow only.  Returns whether any lane appended; the wave has then waited
 // for every vector memory operation it had issued before this call (the atomic's result is the last of them).
-__device__ __forceinline__ bool shade_append(const ShadeOut& out, uint32_t* n_out_ptr, uint32_t cap, rt_f4* oa, rt_f4* ob, rt_f4* oc) {
+__device__ __forceinline__ bool shade_append(const ShadeOut& out, uint32_t* n_out_ptr, uint32_t* overflow, uint32_t cap, rt_f4* oa, rt_f4* ob, rt_f4* oc) {
     unsigned long long mask = __ballot(out.alive);
     if (!mask) return false;
     uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -357,7 +364,10 @@ __device__ __forceinline__ bool shade_append(const ShadeOut& out, uint32_t* n_ou
     if (out.alive && rank == 0) slot0 = atomicAdd(n_out_ptr, (uint32_t)__popcll(mask));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     slot0 = __shfl(slot0, __ffsll((long long)mask) - 1);
-    if (out.alive && slot0 + rank < cap) {  // the capacity bound holds by construction; the test only guards memory
+    // The capacity bound holds by construction (see the top of the file); should it ever fail, the ray is dropped, the
+    // overflow counter says so and the render call returns RT_ERR_INTERNAL instead of a biased image.
+    if (out.alive && slot0 + rank >= cap) atomicAdd(overflow, 1u);
+    else if (out.alive) {
         uint32_t slot = slot0 + rank;
         *reinterpret_cast<float4*>(oa + slot) = make_float4(out.na.x, out.na.y, out.na.z, out.na.w);
         *reinterpret_cast<float4*>(ob + slot) = make_float4(out.nb.x, out.nb.y, out.nb.z, out.nb.w);
@@ -369,10 +379,10 @@ __device__ __forceinline__ bool shade_append(const ShadeOut& out, uint32_t* n_ou
 // One ray per lane, grid-stride, tables from global memory (any scene).  The input queue region is blockIdx.y.
 template <bool STATS>
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev fr, int bounce, uint32_t cap, const uint32_t* counts_in,
-                                                    uint32_t* counts_out, const rt_f4* ia, const rt_f4* ib, const rt_f4* ic,
+                                                    uint32_t* counts_out, uint32_t* overflow, const rt_f4* ia, const rt_f4* ib, const rt_f4* ic,
                                                     const rt_f4* hits, rt_f4* oa, rt_f4* ob, rt_f4* oc, rt_f4* contrib,
                                                     unsigned long long* work) {
-    const uint32_t n = counts_in[blockIdx.y * RT_COUNT_STRIDE];
+    const uint32_t n = min(counts_in[blockIdx.y * RT_COUNT_STRIDE], cap);
     if (blockIdx.x * RT_BLOCK >= n) return;
     // the medium records are the same for every ray: one LDS copy per block instead of a chain of fetches per ray
     __shared__ __align__(16) rt_f4 s_media[RT_SHADE_MEDIA_LDS * RT_MEDIUM_F4];
@@ -389,7 +399,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev f
     auto shade = [&](uint32_t i, bool valid, bool may_postpone) -> bool {
         ShadeOut out; shade_out_clear(out);
         if (valid) shade_ray<STATS>(sc, tab, msrc, fr, bounce, ld4(ia + i), ld4(ib + i), ld4(ic + i), ld4(hits + i), may_postpone, contrib, work, out);
-        shade_append(out, n_out_ptr, cap, oa, ob, oc);
+        shade_append(out, n_out_ptr, overflow, cap, oa, ob, oc);
         return out.postponed;
     };
 
@@ -487,9 +497,9 @@ __device__ __forceinline__ void shade_stage(const rt_f4* ia, const rt_f4* ib, co
 // array in LDS, and no closest-hit kernel runs: the hit record never exists in memory and the ray record is read once.
 template <bool FUSED>
 __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan pl, RtFrameDev fr, int bounce, uint32_t cap, const uint32_t* counts_in,
-                                                    uint32_t* counts_out, const rt_f4* ia, const rt_f4* ib, const rt_f4* ic,
+                                                    uint32_t* counts_out, uint32_t* overflow, const rt_f4* ia, const rt_f4* ib, const rt_f4* ic,
                                                     const rt_f4* hits, rt_f4* oa, rt_f4* ob, rt_f4* oc, rt_f4* contrib) {
-    const uint32_t n = counts_in[blockIdx.y * RT_COUNT_STRIDE];
+    const uint32_t n = min(counts_in[blockIdx.y * RT_COUNT_STRIDE], cap);
     if (blockIdx.x * 1024u >= n) return;
     extern __shared__ __align__(16) unsigned char smem[];
     {   // tables -> LDS
@@ -549,7 +559,7 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
             if (FUSED) h = closest(a, b);
             shade_ray<false>(sc, tab, tab, fr, bounce, a, b, c, h, may_postpone, contrib, nullptr, out);
         }
-        landed = shade_append(out, n_out_ptr, cap, oa, ob, oc);
+        landed = shade_append(out, n_out_ptr, overflow, cap, oa, ob, oc);
         unsigned long long pm = __ballot(out.postponed);
         if (pm) {
             uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
@@ -562,7 +572,7 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
                 ShadeOut o2; shade_out_clear(o2);
                 { rt_f4 a2 = ld4(ia + j), b2 = ld4(ib + j);
                   shade_ray<false>(sc, tab, tab, fr, bounce, a2, b2, ld4(ic + j), FUSED ? closest(a2, b2) : ld4(hits + j), false, contrib, nullptr, o2); }
-                shade_append(o2, n_out_ptr, cap, oa, ob, oc);
+                shade_append(o2, n_out_ptr, overflow, cap, oa, ob, oc);
                 landed = true;                                         // those loads were issued after the staging and have returned
             }
         }
@@ -575,7 +585,7 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
             rt_f4 a2 = ld4(ia + j), b2 = ld4(ib + j);
             shade_ray<false>(sc, tab, tab, fr, bounce, a2, b2, ld4(ic + j), FUSED ? closest(a2, b2) : ld4(hits + j), false, contrib, nullptr, o2);
         }
-        shade_append(o2, n_out_ptr, cap, oa, ob, oc);
+        shade_append(o2, n_out_ptr, overflow, cap, oa, ob, oc);
     }
 }
 
@@ -591,6 +601,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const rt_f4* contrib, i
     }
     accum[3 * (size_t)pixel] += sx; accum[3 * (size_t)pixel + 1] += sy; accum[3 * (size_t)pixel + 2] += sz;
     if (accum_sq) { accum_sq[3 * (size_t)pixel] += qx; accum_sq[3 * (size_t)pixel + 1] += qy; accum_sq[3 * (size_t)pixel + 2] += qz; }
+}
+
+// folded[row] = sum over the regions of counts[row][region]: the rays that entered bounce `row` (row 0: the overflow counter),
+// so that the host reads back 8 bytes per bounce instead of the counter lines.
+__global__ __launch_bounds__(RT_BLOCK) void k_fold_counts(const uint32_t* counts, int rows, unsigned long long* folded) {
+    int row = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (row >= rows) return;
+    unsigned long long sum = 0;
+    for (int sh = 0; sh < RT_SHARDS; ++sh) sum += counts[((size_t)row * RT_SHARDS + sh) * RT_COUNT_STRIDE];
+    folded[row] = sum;
 }
 
 // Parity hook: closest hit of one sample per pixel.
@@ -643,8 +663,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_scatter_rays(RtSceneView sc, const
 }
 
 // ------------------------------------------------------------------ host side
-struct DevBuf {
-    void* p = nullptr; size_t bytes = 0;
+// Device memory of one wavefront pass: the two ray queues (three float4 streams each), the hit stream, one contribution slot
+// per path and the counters.  A scene owns a grow-only one (hipMalloc).
+struct Workspace {
+    size_t paths = 0, cap = 0;             // paths it was sized for; slots per queue region
+    rt_f4 *qa[2] = {nullptr, nullptr}, *qb[2] = {nullptr, nullptr}, *qc[2] = {nullptr, nullptr}, *contrib = nullptr, *hits = nullptr;
+    // counts: `rows` rows of [region] queue sizes (row b = rays entering bounce b; word 0 of row 0, which no bounce uses, is the
+    // overflow counter), then `rows` rows of k_trace cursors.  folded: per row, the sum over the regions (k_fold_counts).
+    uint32_t* counts = nullptr;
+    unsigned long long* folded = nullptr;
+    int rows = 0;
+    unsigned long long* work = nullptr;    // 32 work counters of the instrumented kernels; null: no instrumented runs on this workspace
 };
 struct RtScene {
     int device = 0, n_cu = 0;
@@ -652,14 +681,10 @@ struct RtScene {
     RtSceneView view;              // device pointers
     std::vector<void*> allocs;     // scene arrays
     uint64_t device_bytes = 0;
-    // render workspace (grow-only)
-    size_t ws_paths = 0, ws_cap = 0;   // paths the workspace was sized for; slots per queue region
-    rt_f4 *qa[2] = {nullptr, nullptr}, *qb[2] = {nullptr, nullptr}, *qc[2] = {nullptr, nullptr}, *contrib = nullptr, *hits = nullptr;
-    uint32_t* counts = nullptr;            // [bounce][region] queue sizes, then [bounce][region] trace cursors
+    Workspace ws;                          // render workspace (grow-only)
     RtTracePlan plan;                      // k_trace: what lives in the block's LDS
     int lds_bytes = 0;                     // k_trace: dynamic LDS size
     unsigned trace_gx = 1;                 // k_trace: blocks per region
-    unsigned long long* work = nullptr;   // 16 work counters of the instrumented kernel
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<hipEvent_t> ev_trace;      // per-bounce event pairs around k_trace (RT_FLAG_TIME_TRACE)
     const rt_f4* nodes_on_device = nullptr; // set when the top level was built on the GPU (the node array is already there)
@@ -670,21 +695,23 @@ struct RtScene {
     bool shade_fused = false;              // ... and the BVH is a handful of nodes: k_shade_lds<true> finds the closest hits too, k_trace is not run
     RtShadePlan shade_plan;                // k_shade_lds: layout of the block's LDS
     int shade_lds_bytes = 0;
+    // rt_render_multi: this GPU's private accumulators and stream (grow-only)
+    float *multi_acc = nullptr, *multi_sq = nullptr; size_t multi_floats = 0; hipStream_t multi_stream = nullptr;
 };
 
 static const int kLdsBudget = 160 * 1024 - 512;   // dynamic LDS a 1024-thread block may ask for (one block per CU)
 
 // k_trace comes in two block shapes: 1024 threads (one block per CU; its 16 waves share one LDS copy of the scene) and,
 // where a workgroup cannot have that much LDS, 256 threads (four blocks per CU, each with a 40 KB plan).
-static void launch_trace(RtScene* s, bool stats, hipStream_t st, uint32_t cap, const uint32_t* cin, uint32_t* cursors,
+static void launch_trace(RtScene* s, const Workspace& ws, bool stats, hipStream_t st, uint32_t cap, const uint32_t* cin, uint32_t* cursors,
                          const rt_f4* qa, const rt_f4* qb) {
     dim3 grid(s->trace_gx, RT_SHARDS);
 #define RT_LAUNCH_TRACE(TB_, WIDE_, RES_)                                                                                     \
     do {                                                                                                                      \
         if (stats) hipLaunchKernelGGL((k_trace<true, TB_, WIDE_, RES_>), grid, dim3(TB_), (size_t)s->lds_bytes, st, s->view, s->plan, cap, \
-                                      cin, cursors, qa, qb, s->hits, s->work);                                                \
+                                      cin, cursors, qa, qb, ws.hits, ws.work);                                                \
         else hipLaunchKernelGGL((k_trace<false, TB_, WIDE_, RES_>), grid, dim3(TB_), (size_t)s->lds_bytes, st, s->view, s->plan, cap,      \
-                                cin, cursors, qa, qb, s->hits, s->work);                                                      \
+                                cin, cursors, qa, qb, ws.hits, ws.work);                                                      \
     } while (0)
     if (s->trace_block == 1024 && s->plan.resident) RT_LAUNCH_TRACE(1024, false, true);
     else if (s->trace_block == 1024 && !s->plan.wide_stack) RT_LAUNCH_TRACE(1024, false, false);
@@ -821,32 +848,41 @@ static int upload(RtScene* s, const std::vector<T>& v, const T** out) {
     return RT_OK;
 }
 
-static void free_workspace(RtScene* s) {
-    for (int i = 0; i < 2; ++i) { if (s->qa[i]) (void)hipFree(s->qa[i]); if (s->qb[i]) (void)hipFree(s->qb[i]); if (s->qc[i]) (void)hipFree(s->qc[i]); s->qa[i] = s->qb[i] = s->qc[i] = nullptr; }
-    if (s->contrib) (void)hipFree(s->contrib);
-    if (s->hits) (void)hipFree(s->hits);
-    s->hits = nullptr;
-    s->contrib = nullptr; s->ws_paths = 0; s->ws_cap = 0;
+static void free_queues(Workspace& w) {
+    for (int i = 0; i < 2; ++i) { if (w.qa[i]) (void)hipFree(w.qa[i]); if (w.qb[i]) (void)hipFree(w.qb[i]); if (w.qc[i]) (void)hipFree(w.qc[i]); w.qa[i] = w.qb[i] = w.qc[i] = nullptr; }
+    if (w.contrib) (void)hipFree(w.contrib);
+    if (w.hits) (void)hipFree(w.hits);
+    w.hits = nullptr; w.contrib = nullptr; w.paths = 0; w.cap = 0;
+}
+// Slots per queue region for a pass of n_paths paths (see the capacity argument at the top of the file).
+static size_t region_cap(size_t n_paths) {
+    size_t cap = (n_paths + RT_SHARDS - 1) / RT_SHARDS + (size_t)1024 * (RT_SHARDS + 2);
+    return (cap + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK;
 }
 static int ensure_workspace(RtScene* s, size_t n_paths) {
-    if (!s->counts) { HIP_TRY(hipMalloc((void**)&s->counts, (size_t)2 * (RT_MAX_BOUNCES + 2) * RT_SHARDS * RT_COUNT_STRIDE * sizeof(uint32_t))); }
-    if (!s->work) { HIP_TRY(hipMalloc((void**)&s->work, 32 * sizeof(unsigned long long))); }
-    if (!s->ev0) { HIP_TRY(hipEventCreate(&s->ev0)); HIP_TRY(hipEventCreate(&s->ev1)); }
-    if (s->ws_paths >= n_paths) return RT_OK;
-    free_workspace(s);
-    size_t cap = (n_paths + RT_SHARDS - 1) / RT_SHARDS + (size_t)1024 * (RT_SHARDS + 2);
-    cap = (cap + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK;
-    for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipMalloc((void**)&s->qa[i], cap * RT_SHARDS * sizeof(rt_f4)));
-        HIP_TRY(hipMalloc((void**)&s->qb[i], cap * RT_SHARDS * sizeof(rt_f4)));
-        HIP_TRY(hipMalloc((void**)&s->qc[i], cap * RT_SHARDS * sizeof(rt_f4)));
+    Workspace& w = s->ws;
+    if (!w.counts) {
+        w.rows = RT_MAX_BOUNCES + 2;
+        HIP_TRY(hipMalloc((void**)&w.counts, (size_t)2 * w.rows * RT_SHARDS * RT_COUNT_STRIDE * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&w.folded, (size_t)w.rows * sizeof(unsigned long long)));
     }
-    HIP_TRY(hipMalloc((void**)&s->contrib, n_paths * sizeof(rt_f4)));
-    HIP_TRY(hipMalloc((void**)&s->hits, cap * RT_SHARDS * sizeof(rt_f4)));
-    s->ws_paths = n_paths; s->ws_cap = cap;
+    if (!w.work) { HIP_TRY(hipMalloc((void**)&w.work, 32 * sizeof(unsigned long long))); }
+    if (!s->ev0) { HIP_TRY(hipEventCreate(&s->ev0)); HIP_TRY(hipEventCreate(&s->ev1)); }
+    if (w.paths >= n_paths) return RT_OK;
+    free_queues(w);
+    size_t cap = region_cap(n_paths);
+    // test hook: a deliberately small region capacity makes the queues overflow, which must be reported, not rendered
+    if (const char* e = std::getenv("RT_DEBUG_QUEUE_CAP")) { long v = std::atol(e); if (v > 0) cap = std::min(cap, ((size_t)v + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK); }
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipMalloc((void**)&w.qa[i], cap * RT_SHARDS * sizeof(rt_f4)));
+        HIP_TRY(hipMalloc((void**)&w.qb[i], cap * RT_SHARDS * sizeof(rt_f4)));
+        HIP_TRY(hipMalloc((void**)&w.qc[i], cap * RT_SHARDS * sizeof(rt_f4)));
+    }
+    HIP_TRY(hipMalloc((void**)&w.contrib, n_paths * sizeof(rt_f4)));
+    HIP_TRY(hipMalloc((void**)&w.hits, cap * RT_SHARDS * sizeof(rt_f4)));
+    w.paths = n_paths; w.cap = cap;
     return RT_OK;
 }
-
 static int check_common(const RtScene* s, const RtCamera* cam, const RtRenderParams* p) {
     if (!s || !cam || !p) return rt_set_error(RT_ERR_INVALID, "null argument");
     if (p->width < 2 || p->height < 2) return rt_set_error(RT_ERR_INVALID, "width and height must be >= 2 (main.rs:572-573 divides by W-1, H-1)");
@@ -994,9 +1030,13 @@ void rt_scene_destroy(RtScene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (void* p : s->allocs) (void)hipFree(p);
-    free_workspace(s);
-    if (s->counts) (void)hipFree(s->counts);
-    if (s->work) (void)hipFree(s->work);
+    free_queues(s->ws);
+    if (s->ws.counts) (void)hipFree(s->ws.counts);
+    if (s->ws.folded) (void)hipFree(s->ws.folded);
+    if (s->ws.work) (void)hipFree(s->ws.work);
+    if (s->multi_acc) (void)hipFree(s->multi_acc);
+    if (s->multi_sq) (void)hipFree(s->multi_sq);
+    if (s->multi_stream) (void)hipStreamDestroy(s->multi_stream);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     for (hipEvent_t e : s->ev_trace) (void)hipEventDestroy(e);
@@ -1022,6 +1062,119 @@ int rt_flat_info(const RtFlat* f, RtSceneInfo* out) {
     return RT_OK;
 }
 
+}  // extern "C"
+
+// The passes of one render call on workspace `ws`: samples [sample_offset, sample_offset + spp) of every pixel, `chunk_max`
+// samples per pass.  Everything is enqueued on `st`.  h_folded (max_depth + 2 words, or null) receives the per-bounce ray
+// counts of each pass: the stream is then synchronised once per pass and `local` is complete on return; with null nothing is
+// read back and the call returns with the work still in flight.  Events are recorded only when the scene's are given.
+static int render_passes(RtScene* s, const Workspace& ws, const RtCamera* cam, const RtRenderParams* p, int chunk_max, float* d_accum, float* sq,
+                         hipStream_t st, bool use_events, unsigned long long* h_folded, RtStats& local) {
+    RtCameraDev cd; make_cam(cam, cd);
+    RtFrameDev fr; make_frame(p, fr);
+    const size_t n_pixels = (size_t)fr.n_pixels;
+    const size_t row_words = (size_t)RT_SHARDS * RT_COUNT_STRIDE;
+    const size_t counts_bytes = (size_t)(p->max_depth + 2) * row_words * sizeof(uint32_t);
+    uint32_t* overflow = ws.counts;                                  // word 0 of row 0
+    // k_shade / k_raygen blocks per CU in the grid (grid-stride loops).  With costly textures in the scene each wave should
+    // see many rays, so that the hits it postpones add up to full waves: then the grid is just what is resident.
+    int shade_bpc = s->view.n_perlin > 0 ? 4 : 32;
+    if (const char* e = std::getenv("RT_SHADE_BLOCKS_PER_CU")) shade_bpc = std::max(1, std::min(64, std::atoi(e)));
+    const int grid_cap = std::max(1, s->n_cu) * shade_bpc;
+    const uint32_t cap = (uint32_t)ws.cap;
+    const bool instrumented = (p->flags & RT_FLAG_COUNTERS) != 0;
+    const bool time_trace = use_events && (p->flags & RT_FLAG_TIME_TRACE) != 0;
+    if (time_trace) {
+        while ((int)s->ev_trace.size() < 2 * p->max_depth) { hipEvent_t e = nullptr; HIP_TRY(hipEventCreate(&e)); s->ev_trace.push_back(e); }
+    }
+    const bool debug_work = ws.work && std::getenv("RT_DEBUG_WORK") != nullptr;
+    if (instrumented || debug_work) HIP_TRY(hipMemsetAsync(ws.work, 0, 32 * sizeof(unsigned long long), st));
+
+    for (int done = 0; done < p->spp;) {
+        int chunk = std::min(chunk_max, p->spp - done);
+        uint32_t n_paths = (uint32_t)((size_t)chunk * n_pixels);
+        fr.spp_chunk = chunk; fr.sample_base = p->sample_offset + done;
+        HIP_TRY(hipMemsetAsync(ws.counts, 0, counts_bytes, st));
+        HIP_TRY(hipMemsetAsync(ws.counts + (size_t)ws.rows * row_words, 0, counts_bytes, st));
+        int grid = (int)std::min<size_t>(((size_t)n_paths + RT_BLOCK - 1) / RT_BLOCK, (size_t)grid_cap);
+        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, cd, fr, n_paths, cap, ws.counts + row_words, overflow, ws.qa[0], ws.qb[0], ws.qc[0], ws.contrib);
+        // bounce grid: x = blocks per region (a multiple of RT_SHARDS, see the capacity argument above), y = region
+        int gx = (int)std::min<size_t>(((size_t)n_paths / RT_SHARDS + RT_BLOCK - 1) / RT_BLOCK + 1, (size_t)grid_cap / RT_SHARDS);
+        gx = std::max(RT_SHARDS, (gx + RT_SHARDS - 1) / RT_SHARDS * RT_SHARDS);
+        dim3 bgrid((unsigned)gx, RT_SHARDS);
+        // k_shade_lds: one 1024-thread block per CU, also a multiple of RT_SHARDS blocks per region
+        dim3 lgrid((unsigned)std::max(RT_SHARDS, s->n_cu / RT_SHARDS / RT_SHARDS * RT_SHARDS), RT_SHARDS);
+        HIP_TRY(hipGetLastError());
+        if (use_events) HIP_TRY(hipEventRecord(s->ev0, st));
+        for (int b = 1; b <= p->max_depth; ++b) {
+            int in = (b - 1) & 1, outq = b & 1;
+            const uint32_t* cin = ws.counts + (size_t)b * row_words;
+            uint32_t* cout = ws.counts + (size_t)(b + 1) * row_words;
+            uint32_t* cursors = ws.counts + (size_t)(ws.rows + b) * row_words;
+            if (time_trace) HIP_TRY(hipEventRecord(s->ev_trace[2 * (b - 1)], st));
+            const bool fused = s->shade_fused && !instrumented;
+            if (!fused) launch_trace(s, ws, instrumented, st, cap, cin, cursors, ws.qa[in], ws.qb[in]);
+            if (time_trace) HIP_TRY(hipEventRecord(s->ev_trace[2 * (b - 1) + 1], st));
+            if (instrumented)
+                hipLaunchKernelGGL(k_shade<true>, bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, cin, cout, overflow, ws.qa[in], ws.qb[in], ws.qc[in], ws.hits,
+                                   ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib, ws.work);
+            else if (fused)
+                hipLaunchKernelGGL(k_shade_lds<true>, lgrid, dim3(1024), (size_t)s->shade_lds_bytes, st, s->view, s->shade_plan, fr, b, cap, cin, cout, overflow,
+                                   ws.qa[in], ws.qb[in], ws.qc[in], ws.hits, ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib);
+            else if (s->shade_lds)
+                hipLaunchKernelGGL(k_shade_lds<false>, lgrid, dim3(1024), (size_t)s->shade_lds_bytes, st, s->view, s->shade_plan, fr, b, cap, cin, cout, overflow,
+                                   ws.qa[in], ws.qb[in], ws.qc[in], ws.hits, ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib);
+            else
+                hipLaunchKernelGGL(k_shade<false>, bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, cin, cout, overflow, ws.qa[in], ws.qb[in], ws.qc[in], ws.hits,
+                                   ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib, ws.work);
+        }
+        HIP_TRY(hipGetLastError());
+        if (use_events) HIP_TRY(hipEventRecord(s->ev1, st));
+        int agrid = (int)((n_pixels + RT_BLOCK - 1) / RT_BLOCK);
+        hipLaunchKernelGGL(k_accumulate, dim3(agrid), dim3(RT_BLOCK), 0, st, ws.contrib, (int)n_pixels, chunk, d_accum, sq);
+        HIP_TRY(hipGetLastError());
+        local.passes++;
+        done += chunk;
+        if (!h_folded) continue;
+        const int rows = p->max_depth + 2;
+        hipLaunchKernelGGL(k_fold_counts, dim3((rows + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, ws.counts, rows, ws.folded);
+        HIP_TRY(hipMemcpyAsync(h_folded, ws.folded, (size_t)rows * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h_folded[0] != 0)
+            return rt_set_error(RT_ERR_INTERNAL, "ray queue overflow: " + std::to_string(h_folded[0]) + " rays did not fit their queue region (the image is incomplete)");
+        if (use_events) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+            local.kernel_ms_extend += ms; local.extend_launches += (uint64_t)p->max_depth;
+        }
+        if (time_trace) {
+            for (int b = 0; b < p->max_depth; ++b) {
+                float tms = 0.0f;
+                HIP_TRY(hipEventElapsedTime(&tms, s->ev_trace[2 * b], s->ev_trace[2 * b + 1]));
+                local.kernel_ms_trace += tms;
+            }
+            local.trace_launches += (uint64_t)p->max_depth;
+        }
+        for (int b = 1; b <= p->max_depth; ++b) {
+            local.rays += h_folded[b];
+            if (b <= 64) local.rays_per_bounce[b - 1] += h_folded[b];
+        }
+    }
+    if (instrumented && h_folded) {
+        unsigned long long w[16];
+        HIP_TRY(hipMemcpy(w, ws.work, sizeof(w), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 16; ++i) local.work[i] = w[i];
+    }
+    if (debug_work && h_folded) {   // developer output: wave-level counters of the instrumented k_trace
+        unsigned long long w2[16];
+        HIP_TRY(hipMemcpy(w2, ws.work + 16, sizeof(w2), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "k_trace wave counters: outer %llu refills %llu node-iters %llu leaf-iters %llu\n", w2[0], w2[1], w2[2], w2[3]);
+    }
+    return RT_OK;
+}
+
+extern "C" {
+
 int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* d_accum, float* d_accum_sq, void* hip_stream, RtStats* stats) {
     int rc = check_common(s, cam, p);
     if (rc) return rc;
@@ -1031,10 +1184,7 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     hipStream_t st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(s->device));
     auto t_begin = std::chrono::steady_clock::now();
-
-    RtCameraDev cd; make_cam(cam, cd);
-    RtFrameDev fr; make_frame(p, fr);
-    const size_t n_pixels = (size_t)fr.n_pixels;
+    const size_t n_pixels = (size_t)p->width * (size_t)p->height;
     // Default pass: up to 2^28 paths in flight (34 GB of queues, hit and contribution slots on a 288 GB part).  Late
     // bounces hold few rays per launch and run below the bulk rate; the more paths share a pass, the less that costs
     // (final_scene.yml: +10 % from 2^26 to 2^28).
@@ -1045,105 +1195,17 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     // The default pass is sized for an otherwise empty 288 GB part; when the workspace does not fit (other tenants, several
     // scene handles) the pass is halved until it does.  An explicit paths_per_pass is taken as given.
     while ((rc = ensure_workspace(s, (size_t)chunk_max * n_pixels)) == RT_ERR_OOM && p->paths_per_pass <= 0 && chunk_max > 1) {
-        free_workspace(s);
+        free_queues(s->ws);
         (void)hipGetLastError();
         chunk_max = (chunk_max + 1) / 2;
     }
     if (rc) return rc;
-
     RtStats local; std::memset(&local, 0, sizeof(local));
     local.paths = (uint64_t)n_pixels * (uint64_t)p->spp;
-    std::vector<uint32_t> h_counts((size_t)(p->max_depth + 2) * RT_SHARDS * RT_COUNT_STRIDE);
-    const size_t counts_bytes = h_counts.size() * sizeof(uint32_t);
-    // k_shade / k_raygen blocks per CU in the grid (grid-stride loops).  With costly textures in the scene each wave should
-    // see many rays, so that the hits it postpones add up to full waves: then the grid is just what is resident.
-    int shade_bpc = s->view.n_perlin > 0 ? 4 : 32;
-    if (const char* e = std::getenv("RT_SHADE_BLOCKS_PER_CU")) shade_bpc = std::max(1, std::min(64, std::atoi(e)));
-    const int grid_cap = std::max(1, s->n_cu) * shade_bpc;
-    const uint32_t cap = (uint32_t)s->ws_cap;
+    std::vector<unsigned long long> h_folded((size_t)p->max_depth + 2);
     float* sq = (p->flags & RT_FLAG_SUMSQ) ? d_accum_sq : nullptr;
-    const bool instrumented = (p->flags & RT_FLAG_COUNTERS) != 0;
-    const bool time_trace = (p->flags & RT_FLAG_TIME_TRACE) != 0;
-    if (time_trace) {
-        while ((int)s->ev_trace.size() < 2 * p->max_depth) { hipEvent_t e = nullptr; HIP_TRY(hipEventCreate(&e)); s->ev_trace.push_back(e); }
-    }
-    const bool debug_work = std::getenv("RT_DEBUG_WORK") != nullptr;
-    if (instrumented || debug_work) HIP_TRY(hipMemsetAsync(s->work, 0, 32 * sizeof(unsigned long long), st));
-
-    for (int done = 0; done < p->spp;) {
-        int chunk = std::min(chunk_max, p->spp - done);
-        uint32_t n_paths = (uint32_t)((size_t)chunk * n_pixels);
-        fr.spp_chunk = chunk; fr.sample_base = p->sample_offset + done;
-        HIP_TRY(hipMemsetAsync(s->counts, 0, counts_bytes, st));
-        HIP_TRY(hipMemsetAsync(s->counts + (size_t)(RT_MAX_BOUNCES + 2) * RT_SHARDS * RT_COUNT_STRIDE, 0, counts_bytes, st));
-        int grid = (int)std::min<size_t>(((size_t)n_paths + RT_BLOCK - 1) / RT_BLOCK, (size_t)grid_cap);
-        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, cd, fr, n_paths, cap, s->counts + RT_SHARDS * RT_COUNT_STRIDE, s->qa[0], s->qb[0], s->qc[0], s->contrib);
-        // bounce grid: x = blocks per region (a multiple of RT_SHARDS, see the capacity argument above), y = region
-        int gx = (int)std::min<size_t>(((size_t)n_paths / RT_SHARDS + RT_BLOCK - 1) / RT_BLOCK + 1, (size_t)grid_cap / RT_SHARDS);
-        gx = std::max(RT_SHARDS, (gx + RT_SHARDS - 1) / RT_SHARDS * RT_SHARDS);
-        dim3 bgrid((unsigned)gx, RT_SHARDS);
-        // k_shade_lds: one 1024-thread block per CU, also a multiple of RT_SHARDS blocks per region
-        dim3 lgrid((unsigned)std::max(RT_SHARDS, s->n_cu / RT_SHARDS / RT_SHARDS * RT_SHARDS), RT_SHARDS);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(s->ev0, st));
-        for (int b = 1; b <= p->max_depth; ++b) {
-            int in = (b - 1) & 1, outq = b & 1;
-            const uint32_t* cin = s->counts + (size_t)b * RT_SHARDS * RT_COUNT_STRIDE;
-            uint32_t* cout = s->counts + (size_t)(b + 1) * RT_SHARDS * RT_COUNT_STRIDE;
-            uint32_t* cursors = s->counts + (size_t)(RT_MAX_BOUNCES + 2 + b) * RT_SHARDS * RT_COUNT_STRIDE;
-            if (time_trace) HIP_TRY(hipEventRecord(s->ev_trace[2 * (b - 1)], st));
-            const bool fused = s->shade_fused && !instrumented;
-            if (!fused) launch_trace(s, instrumented, st, cap, cin, cursors, s->qa[in], s->qb[in]);
-            if (time_trace) HIP_TRY(hipEventRecord(s->ev_trace[2 * (b - 1) + 1], st));
-            if (instrumented)
-                hipLaunchKernelGGL(k_shade<true>, bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, cin, cout, s->qa[in], s->qb[in], s->qc[in], s->hits,
-                                   s->qa[outq], s->qb[outq], s->qc[outq], s->contrib, s->work);
-            else if (fused)
-                hipLaunchKernelGGL(k_shade_lds<true>, lgrid, dim3(1024), (size_t)s->shade_lds_bytes, st, s->view, s->shade_plan, fr, b, cap, cin, cout,
-                                   s->qa[in], s->qb[in], s->qc[in], s->hits, s->qa[outq], s->qb[outq], s->qc[outq], s->contrib);
-            else if (s->shade_lds)
-                hipLaunchKernelGGL(k_shade_lds<false>, lgrid, dim3(1024), (size_t)s->shade_lds_bytes, st, s->view, s->shade_plan, fr, b, cap, cin, cout,
-                                   s->qa[in], s->qb[in], s->qc[in], s->hits, s->qa[outq], s->qb[outq], s->qc[outq], s->contrib);
-            else
-                hipLaunchKernelGGL(k_shade<false>, bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, cin, cout, s->qa[in], s->qb[in], s->qc[in], s->hits,
-                                   s->qa[outq], s->qb[outq], s->qc[outq], s->contrib, s->work);
-        }
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(s->ev1, st));
-        int agrid = (int)((n_pixels + RT_BLOCK - 1) / RT_BLOCK);
-        hipLaunchKernelGGL(k_accumulate, dim3(agrid), dim3(RT_BLOCK), 0, st, s->contrib, (int)n_pixels, chunk, d_accum, sq);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h_counts.data(), s->counts, counts_bytes, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        float ms = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
-        local.kernel_ms_extend += ms; local.extend_launches += (uint64_t)p->max_depth; local.passes++;
-        if (time_trace) {
-            for (int b = 0; b < p->max_depth; ++b) {
-                float tms = 0.0f;
-                HIP_TRY(hipEventElapsedTime(&tms, s->ev_trace[2 * b], s->ev_trace[2 * b + 1]));
-                local.kernel_ms_trace += tms;
-            }
-            local.trace_launches += (uint64_t)p->max_depth;
-        }
-        for (int b = 1; b <= p->max_depth; ++b) {
-            uint64_t nb = 0;
-            for (int sh = 0; sh < RT_SHARDS; ++sh) nb += h_counts[((size_t)b * RT_SHARDS + sh) * RT_COUNT_STRIDE];
-            local.rays += nb;
-            if (b <= 64) local.rays_per_bounce[b - 1] += nb;
-        }
-        done += chunk;
-    }
-    if (instrumented) {
-        unsigned long long w[16];
-        HIP_TRY(hipMemcpy(w, s->work, sizeof(w), hipMemcpyDeviceToHost));
-        for (int i = 0; i < 16; ++i) local.work[i] = w[i];
-    }
-    if (debug_work) {   // developer output: wave-level counters of the instrumented k_trace
-        unsigned long long w2[16];
-        HIP_TRY(hipMemcpy(w2, s->work + 16, sizeof(w2), hipMemcpyDeviceToHost));
-        std::fprintf(stderr, "k_trace wave counters: outer %llu refills %llu node-iters %llu leaf-iters %llu\n", w2[0], w2[1], w2[2], w2[3]);
-    }
+    rc = render_passes(s, s->ws, cam, p, chunk_max, d_accum, sq, st, true, h_folded.data(), local);
+    if (rc) return rc;
     local.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     if (stats) *stats = local;
     return RT_OK;
@@ -1174,6 +1236,158 @@ int rt_render(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* a
     }
     (void)hipFree(d_acc); if (d_sq) (void)hipFree(d_sq);
     return rc;
+}
+
+int rt_shard_samples(int32_t total_spp, int32_t n_shards, int32_t shard, int32_t* first, int32_t* count) {
+    if (!first || !count || total_spp < 0 || n_shards < 1 || shard < 0 || shard >= n_shards) return rt_set_error(RT_ERR_INVALID, "rt_shard_samples: bad argument");
+    const int32_t base = total_spp / n_shards, extra = total_spp % n_shards;
+    *count = base + (shard < extra ? 1 : 0);
+    *first = shard * base + std::min(shard, extra);
+    return RT_OK;
+}
+
+}  // extern "C"
+
+// ---- RCCL, loaded on first use: a caller that renders on one GPU never needs the library.  When PyTorch is in the process its
+// bundled librccl (same soname) is already mapped and is the one this finds, as with the HIP runtime.
+namespace {
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr; decltype(&ncclCommDestroy) CommDestroy = nullptr; decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr; decltype(&ncclGroupEnd) GroupEnd = nullptr; decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+std::mutex g_rccl_mutex;
+RcclApi g_rccl;
+std::map<std::vector<int>, std::vector<ncclComm_t>> g_rccl_comms;   // one communicator set per ordered device list, kept until the process ends
+
+int rccl_load() {   // g_rccl_mutex held
+    if (g_rccl.handle) return RT_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return rt_set_error(RT_ERR_NCCL, std::string("cannot load librccl: ") + dlerror());
+    RcclApi api; api.handle = h;
+#define RT_SYM(field, name) do { api.field = reinterpret_cast<decltype(api.field)>(dlsym(h, name)); \
+        if (!api.field) return rt_set_error(RT_ERR_NCCL, std::string("librccl lacks ") + name); } while (0)
+    RT_SYM(CommInitAll, "ncclCommInitAll"); RT_SYM(CommDestroy, "ncclCommDestroy"); RT_SYM(Reduce, "ncclReduce");
+    RT_SYM(GroupStart, "ncclGroupStart"); RT_SYM(GroupEnd, "ncclGroupEnd"); RT_SYM(GetErrorString, "ncclGetErrorString");
+#undef RT_SYM
+    g_rccl = api;
+    return RT_OK;
+}
+#define NCCL_TRY(expr)                                                                                       \
+    do {                                                                                                     \
+        ncclResult_t r_ = (expr);                                                                            \
+        if (r_ != ncclSuccess) return rt_set_error(RT_ERR_NCCL, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+// sum over the GPUs of `bufs[i]` (count floats each, on stream streams[i] of device devices[i]) into bufs[0]
+int rccl_reduce_to_first(const std::vector<int>& devices, const std::vector<float*>& bufs, const std::vector<hipStream_t>& streams, size_t count) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    int rc = rccl_load();
+    if (rc) return rc;
+    auto it = g_rccl_comms.find(devices);
+    if (it == g_rccl_comms.end()) {
+        std::vector<ncclComm_t> comms(devices.size());
+        NCCL_TRY(g_rccl.CommInitAll(comms.data(), (int)devices.size(), devices.data()));
+        it = g_rccl_comms.emplace(devices, comms).first;
+    }
+    NCCL_TRY(g_rccl.GroupStart());
+    for (size_t i = 0; i < devices.size(); ++i) {
+        HIP_TRY(hipSetDevice(devices[i]));
+        NCCL_TRY(g_rccl.Reduce(bufs[i], bufs[i], count, ncclFloat32, ncclSum, 0, it->second[i], streams[i]));
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+    for (size_t i = 0; i < devices.size(); ++i) { HIP_TRY(hipSetDevice(devices[i])); HIP_TRY(hipStreamSynchronize(streams[i])); }
+    return RT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int rt_render_multi(RtScene* const* scenes, int32_t n_scenes, const RtCamera* cam, const RtRenderParams* p, float* accum, float* accum_sq, RtStats* stats) {
+    if (!scenes || n_scenes < 1 || n_scenes > 64) return rt_set_error(RT_ERR_INVALID, "rt_render_multi: need 1..64 scenes");
+    if (!accum) return rt_set_error(RT_ERR_INVALID, "null accumulation buffer");
+    if (p && p->spp < 0) return rt_set_error(RT_ERR_INVALID, "spp must be >= 0");
+    if (p && (p->flags & RT_FLAG_SUMSQ) && !accum_sq) return rt_set_error(RT_ERR_INVALID, "RT_FLAG_SUMSQ needs accum_sq");
+    const int n = n_scenes;
+    std::vector<int> devices(n);
+    for (int i = 0; i < n; ++i) {
+        int rc = check_common(scenes[i], cam, p);
+        if (rc) return rc;
+        devices[i] = scenes[i]->device;
+        for (int j = 0; j < i; ++j)
+            if (devices[j] == devices[i]) return rt_set_error(RT_ERR_INVALID, "rt_render_multi: two scenes on GPU " + std::to_string(devices[i]) + " (one scene handle per GPU)");
+    }
+    auto t_begin = std::chrono::steady_clock::now();
+    const bool want_sq = (p->flags & RT_FLAG_SUMSQ) != 0;
+    const size_t floats = (size_t)p->width * (size_t)p->height * 3;
+    // private accumulators and a stream per GPU
+    for (int i = 0; i < n; ++i) {
+        RtScene* s = scenes[i];
+        HIP_TRY(hipSetDevice(s->device));
+        if (!s->multi_stream) HIP_TRY(hipStreamCreateWithFlags(&s->multi_stream, hipStreamNonBlocking));
+        if (s->multi_floats < floats) {
+            if (s->multi_acc) (void)hipFree(s->multi_acc);
+            if (s->multi_sq) (void)hipFree(s->multi_sq);
+            s->multi_acc = s->multi_sq = nullptr; s->multi_floats = 0;
+            HIP_TRY(hipMalloc((void**)&s->multi_acc, floats * sizeof(float)));
+            HIP_TRY(hipMalloc((void**)&s->multi_sq, floats * sizeof(float)));
+            s->multi_floats = floats;
+        }
+        HIP_TRY(hipMemsetAsync(s->multi_acc, 0, floats * sizeof(float), s->multi_stream));
+        if (want_sq) HIP_TRY(hipMemsetAsync(s->multi_sq, 0, floats * sizeof(float), s->multi_stream));
+    }
+    // GPU i renders its contiguous sample range on its own host thread (rt_render_device synchronises its stream)
+    std::vector<RtStats> st(n);
+    std::vector<int> rcs(n, RT_OK);
+    std::vector<std::string> errs(n);
+    auto work = [&](int i) {
+        RtRenderParams pi = *p;
+        int32_t first = 0, count = 0;
+        rt_shard_samples(p->spp, n, i, &first, &count);
+        pi.spp = count; pi.sample_offset = p->sample_offset + first;
+        std::memset(&st[i], 0, sizeof(RtStats));
+        rcs[i] = rt_render_device(scenes[i], cam, &pi, scenes[i]->multi_acc, want_sq ? scenes[i]->multi_sq : nullptr, scenes[i]->multi_stream, &st[i]);
+        if (rcs[i]) errs[i] = g_rt_error;
+    };
+    {
+        std::vector<std::thread> threads;
+        for (int i = 1; i < n; ++i) threads.emplace_back(work, i);
+        work(0);
+        for (auto& t : threads) t.join();
+    }
+    for (int i = 0; i < n; ++i) if (rcs[i]) return rt_set_error(rcs[i], "GPU " + std::to_string(devices[i]) + ": " + errs[i]);
+    // one reduce(SUM) of W*H*3 floats to the first GPU (the per-pixel sum of src/main.rs:585-589 lifted across GPUs)
+    std::vector<float*> bufs(n); std::vector<hipStream_t> streams(n);
+    for (int i = 0; i < n; ++i) { bufs[i] = scenes[i]->multi_acc; streams[i] = scenes[i]->multi_stream; }
+    int rc = rccl_reduce_to_first(devices, bufs, streams, floats);
+    if (rc) return rc;
+    if (want_sq) {
+        for (int i = 0; i < n; ++i) bufs[i] = scenes[i]->multi_sq;
+        if ((rc = rccl_reduce_to_first(devices, bufs, streams, floats))) return rc;
+    }
+    HIP_TRY(hipSetDevice(devices[0]));
+    std::vector<float> tmp(floats);
+    HIP_TRY(hipMemcpy(tmp.data(), scenes[0]->multi_acc, floats * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < floats; ++k) accum[k] += tmp[k];
+    if (want_sq) {
+        HIP_TRY(hipMemcpy(tmp.data(), scenes[0]->multi_sq, floats * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < floats; ++k) accum_sq[k] += tmp[k];
+    }
+    if (stats) {
+        RtStats tot; std::memset(&tot, 0, sizeof(tot));
+        for (int i = 0; i < n; ++i) {
+            tot.rays += st[i].rays; tot.paths += st[i].paths; tot.passes += st[i].passes;
+            tot.extend_launches += st[i].extend_launches; tot.trace_launches += st[i].trace_launches;
+            tot.kernel_ms_extend = std::max(tot.kernel_ms_extend, st[i].kernel_ms_extend);
+            tot.kernel_ms_trace = std::max(tot.kernel_ms_trace, st[i].kernel_ms_trace);
+            for (int b = 0; b < 64; ++b) tot.rays_per_bounce[b] += st[i].rays_per_bounce[b];
+            for (int k = 0; k < 16; ++k) tot.work[k] += st[i].work[k];
+        }
+        tot.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        *stats = tot;
+    }
+    return RT_OK;
 }
 
 int rt_trace_primary(RtScene* s, const RtCamera* cam, const RtRenderParams* p, int32_t sample, int32_t* ids, float* ts, float* normals,

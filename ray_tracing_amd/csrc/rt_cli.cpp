@@ -18,6 +18,18 @@
 
 static int die(const char* what) { std::fprintf(stderr, "rt_cli: %s: %s\n", what, rt_last_error()); return 1; }
 
+// What a checkpoint's samples were rendered from, besides the render seed and the image size (which the checkpoint file itself
+// holds): the scene seed and an FNV-1a hash of the config file's bytes.  Kept in a text file beside the checkpoint.
+static unsigned long long file_hash(const std::string& path) {
+    unsigned long long h = 1469598103934665603ull;
+    if (FILE* f = std::fopen(path.c_str(), "rb")) {
+        int c;
+        while ((c = std::fgetc(f)) != EOF) { h ^= (unsigned long long)(unsigned char)c; h *= 1099511628211ull; }
+        std::fclose(f);
+    }
+    return h;
+}
+
 int main(int argc, char** argv) {
     std::string config, output = "./image.jpeg", checkpoint;
     long long pass_spp = 1024;
@@ -60,13 +72,26 @@ int main(int argc, char** argv) {
     std::vector<float> accum((size_t)p.width * p.height * 3, 0.0f);
     const int total_spp = p.spp;
     long long done = 0;
+    const std::string origin_path = checkpoint + ".scene";
+    const unsigned long long cfg_hash = file_hash(config);
     if (!checkpoint.empty()) {
         int64_t have = 0; uint64_t ck_seed = 0;
         if (rt_accum_load(checkpoint.c_str(), accum.data(), p.width, p.height, &have, &ck_seed) == RT_OK) {
             if (ck_seed != seed) { std::fprintf(stderr, "rt_cli: %s was rendered with seed %llu, not %llu\n", checkpoint.c_str(), (unsigned long long)ck_seed, (unsigned long long)seed); return 1; }
-            done = std::min<long long>(have, total_spp);
+            if (FILE* f = std::fopen(origin_path.c_str(), "r")) {   // samples of another scene must not be mixed into this image
+                unsigned long long ck_scene = 0, ck_hash = 0;
+                bool ok = std::fscanf(f, "%llu %llu", &ck_scene, &ck_hash) == 2;
+                std::fclose(f);
+                if (ok && (ck_scene != scene_seed || ck_hash != cfg_hash)) {
+                    std::fprintf(stderr, "rt_cli: %s was rendered from another scene (scene seed or config file differ)\n", checkpoint.c_str());
+                    return 1;
+                }
+            }
+            // a checkpoint that already holds more samples than asked for is finished: the image is made from all of them
+            done = have;
             std::fprintf(stderr, "rt_cli: resuming %s at %lld of %d spp\n", checkpoint.c_str(), done, total_spp);
         } else std::fill(accum.begin(), accum.end(), 0.0f);     // no usable checkpoint: start from scratch
+        if (FILE* f = std::fopen(origin_path.c_str(), "w")) { std::fprintf(f, "%llu %llu\n", scene_seed, cfg_hash); std::fclose(f); }
     }
     RtStats st, total; std::memset(&total, 0, sizeof(total));
     while (done < total_spp) {
@@ -77,7 +102,7 @@ int main(int argc, char** argv) {
         done += p.spp;
         if (!checkpoint.empty() && rt_accum_save(checkpoint.c_str(), accum.data(), p.width, p.height, done, seed)) return die("checkpoint");
     }
-    st = total; p.spp = total_spp;
+    st = total; p.spp = (int)std::max<long long>(done, total_spp);   // the number of samples `accum` really holds (utils.rs:52 divides by it)
     std::vector<uint8_t> rgb(accum.size());
     if (rt_tonemap_u8(accum.data(), p.width * p.height, p.spp, rgb.data())) return die("tonemap");
     if (rt_write_image(output.c_str(), rgb.data(), p.width, p.height)) return die("write");

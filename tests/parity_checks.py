@@ -54,9 +54,19 @@ def check_render(backend, ob, cam, width, height, spp, max_depth, background=(0,
     rmse = np.sqrt(((gm - om) ** 2).mean(axis=(0, 1)))
     bound = noise_bound(gm, gsq.astype(np.float64), spp, om, osq, spp)
     assert np.all(rmse <= bound), (rmse, bound)
-    same = np.mean(np.all(np.abs(gm - om) <= 1e-3 * (1 + np.abs(om)), axis=2))
+    same_px = np.all(np.abs(gm - om) <= 1e-3 * (1 + np.abs(om)), axis=2)
+    same = np.mean(same_px)
     assert same >= same_fraction, "only %.4f of the pixels follow the oracle's paths" % same
     assert abs(grays - ost["rays"]) <= 2e-3 * ost["rays"], (grays, ost["rays"])
+    # The pixels that left the oracle's paths (an fp32 decision fell the other way somewhere along a path) must not be biased:
+    # their signed mean difference stays within 3 standard errors of the difference of two independent estimates.
+    off = ~same_px
+    if off.sum() >= 8:
+        var_g = np.maximum(gsq.astype(np.float64) / spp - gm ** 2, 0)[off]
+        var_o = np.maximum(osq / spp - om ** 2, 0)[off]
+        stderr = np.sqrt((var_g + var_o).sum(axis=0) / spp) / off.sum()
+        signed = (gm - om)[off].mean(axis=0)
+        assert np.all(np.abs(signed) <= 3 * stderr + 1e-6), "diverged pixels are biased: mean difference %s, standard error %s" % (signed, stderr)
     return float(rmse.max()), float(bound), float(same)
 
 

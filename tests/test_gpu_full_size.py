@@ -222,6 +222,13 @@ def test_cli_checkpoint_and_resume(gpu_required, tmp_path):
     scene.close()
     want = rt.tonemap_u8(whole, 12)
     assert np.abs(img.astype(int) - want.astype(int)).max() <= 1                    # fp32 summation order only
+    # asking for fewer samples than the checkpoint holds renders nothing and divides by what the buffer holds, not by the request
+    out3 = str(tmp_path / "c.png")
+    run("-o", out3, "--spp", "4", "--checkpoint", ck)
+    assert np.array_equal(decode(out3), img)
+    # samples of another scene are not mixed into the image
+    r = subprocess.run([cli, "-c", cfg, "-o", out3, "--spp", "16", "--checkpoint", ck, "--scene-seed", "7"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "another scene" in r.stderr
 
 
 @pytest.mark.parametrize("name", ["final_scene.yml", "random.yml", "showcase.yml"])

@@ -1,0 +1,168 @@
+"""GPU tests of the stress configuration at its stated size (1 000 000 spheres, 3840x2160), of bias under independent
+seeds at high sample counts, of the queue-overflow report, and of the multi-GPU entry points at the sizes one GPU allows.
+Everything goes through the C ABI (librt_hip.so); the f64 oracle is the checker."""
+import os
+
+import numpy as np
+import pytest
+
+import ray_tracing_amd as rt
+from helpers import RENDER_SEED, SCENE_SEED, OracleBuilder, OracleCamera, config_camera, oracle_render, oracle_trace_primary, primary_agreement, scene_pair
+from parity_checks import ID_AGREEMENT, T_REL_TOL
+
+pytestmark = pytest.mark.gpu
+
+STRESS = "Synthetic:1000000"
+STRESS_CAM = dict(look_from=(0, 260, 1500), look_at=(0, 60, 0), v_up=(0, 1, 0), vfov=40.0, aspect=16 / 9, aperture=0.1, focus_dist=10.0)
+SKY = (0.7, 0.8, 1.0)
+
+
+@pytest.fixture(scope="module")
+def stress_world():
+    """The 1M-sphere field on the product builder and on the oracle (its own builder and its own random-axis median BVH)."""
+    b = rt.Builder()
+    w = b.canned_scene(STRESS, SCENE_SEED)
+    ob = OracleBuilder()
+    ob.set_world(ob.canned_scene(STRESS, SCENE_SEED))
+    return b, w, ob
+
+
+@pytest.mark.parametrize("flags", [0, rt.RT_BVH_LINEAR], ids=["sah_tree", "device_built_linear_tree"])
+def test_one_million_spheres_primary_hits_match_oracle(gpu_required, stress_world, flags):
+    b, w, ob = stress_world
+    scene = rt.Scene(b, w, 0, flags)
+    info = scene.info()
+    assert info.n_spheres == 1000001 and info.max_stack <= 32
+    cam = rt.make_camera(**STRESS_CAM)
+    W, H = 480, 270
+    oc = OracleCamera(cam)
+    for sample in (0, 5):
+        g = scene.trace_primary(cam, rt.render_params(W, H, 1, 50, RENDER_SEED), sample)
+        o = oracle_trace_primary(ob, oc, W, H, sample, RENDER_SEED)
+        agree, rel = primary_agreement(g, o)
+        assert agree >= ID_AGREEMENT and rel <= T_REL_TOL, (agree, rel)
+        assert (o["id"] >= 0).mean() > 0.5 and len(np.unique(o["id"])) > 20000       # the view really is a field of spheres
+    scene.close()
+
+
+def test_one_million_spheres_render_matches_oracle(gpu_required, stress_world):
+    """A small render of the stress scene on a shared Philox stream: path-identical pixels and equal ray counts."""
+    b, w, ob = stress_world
+    scene = rt.Scene(b, w, 0)
+    cam = rt.make_camera(**STRESS_CAM)
+    W, H, spp = 96, 54, 8
+    p = rt.render_params(W, H, spp, 50, RENDER_SEED, background=SKY)
+    ga, _, st = scene.render(cam, p)
+    oa, _, ost = oracle_render(ob, OracleCamera(cam), W, H, spp, 50, RENDER_SEED, background=SKY)
+    same = np.mean(np.all(np.abs(ga / spp - oa / spp) <= 1e-3 * (1 + np.abs(oa / spp)), axis=2))
+    assert same >= 0.97, same
+    assert abs(int(st.rays) - ost["rays"]) <= 2e-3 * ost["rays"]
+    scene.close()
+
+
+def test_one_million_spheres_at_3840x2160(gpu_required, stress_world):
+    """Size-independent properties at the full image size of the stress configuration: determinism, additivity over sample
+    ranges, independence from the pass size, ray conservation; and the two trees give the same image."""
+    b, w, _ = stress_world
+    scene = rt.Scene(b, w, 0)
+    cam = rt.make_camera(**STRESS_CAM)
+    W, H, D, spp = 3840, 2160, 50, 2
+    full, _, st = scene.render(cam, rt.render_params(W, H, spp, D, RENDER_SEED, background=SKY))
+    again, _, st2 = scene.render(cam, rt.render_params(W, H, spp, D, RENDER_SEED, background=SKY))
+    assert np.array_equal(full, again) and st.rays == st2.rays
+    rpb = np.array(list(st.rays_per_bounce[:D]), dtype=np.int64)
+    assert rpb[0] == W * H * spp == st.paths and np.all(np.diff(rpb) <= 0) and rpb.sum() == st.rays <= st.paths * D
+    assert np.isfinite(full).all() and full.min() >= 0 and 0.05 < full.mean() / spp < 1.0 + 1e-6     # nothing emits but the sky
+    parts = np.zeros_like(full)
+    _, _, sa = scene.render(cam, rt.render_params(W, H, 1, D, RENDER_SEED, sample_offset=0, background=SKY), accum=parts)
+    _, _, sb = scene.render(cam, rt.render_params(W, H, 1, D, RENDER_SEED, sample_offset=1, background=SKY), accum=parts)
+    assert sa.rays + sb.rays == st.rays and np.allclose(parts, full, rtol=2e-6, atol=1e-5)
+    small, _, ss = scene.render(cam, rt.render_params(W, H, spp, D, RENDER_SEED, background=SKY, paths_per_pass=W * H))
+    assert ss.rays == st.rays and ss.passes == 2 and np.allclose(small, full, rtol=2e-6, atol=1e-5)
+    scene.close()
+    lin = rt.Scene(b, w, 0, rt.RT_BVH_LINEAR)
+    other, _, sl = lin.render(cam, rt.render_params(W, H, spp, D, RENDER_SEED, background=SKY))
+    assert sl.rays == st.rays and np.array_equal(other, full)
+    lin.close()
+
+
+@pytest.mark.parametrize("name,gpu_spp,cpu_spp", [("cornell.yml", 4096, 1024), ("final_scene.yml", 4096, 1024)])
+def test_converged_images_agree_under_independent_seeds(gpu_required, name, gpu_spp, cpu_spp):
+    """The GPU at 4096 spp with one seed against the oracle at 1024 spp with another: nothing is shared between the two
+    estimates, so a bias of the fp32 path (self-hit exclusion, widened medium re-query, NaN rectangles) cannot hide behind
+    path-by-path agreement.  Per channel: RMSE <= 1.5 sqrt(var_gpu / N_gpu + var_cpu / N_cpu), and the image-wide mean
+    difference within 4 standard errors."""
+    cfg, cam, b, world, ob = scene_pair(name)
+    scene = rt.Scene(b, world, 0)
+    W = H = 64
+    ga, gsq, _ = scene.render(cam, rt.render_params(W, H, gpu_spp, cfg.max_depth, 0xA11CE), want_sumsq=True)
+    oa, osq, _ = oracle_render(ob, OracleCamera(cam), W, H, cpu_spp, cfg.max_depth, 0xB0B, n_threads=16, want_sumsq=True)
+    gm, om = ga.astype(np.float64) / gpu_spp, oa / cpu_spp
+    var_g = np.maximum(gsq.astype(np.float64) / gpu_spp - gm ** 2, 0)
+    var_o = np.maximum(osq / cpu_spp - om ** 2, 0)
+    per_pixel = var_g / gpu_spp + var_o / cpu_spp                       # variance of the difference of the two pixel means
+    rmse = np.sqrt(((gm - om) ** 2).mean(axis=(0, 1)))
+    bound = 1.5 * np.sqrt(per_pixel.mean(axis=(0, 1)))
+    assert np.all(rmse <= bound), (rmse, bound)
+    mean_diff = (gm - om).mean(axis=(0, 1))
+    stderr = np.sqrt(per_pixel.sum(axis=(0, 1))) / (W * H)
+    assert np.all(np.abs(mean_diff) <= 4 * stderr), (mean_diff, stderr)
+    print("%s: rmse %s <= %s; mean difference %s (standard error %s)" % (name, rmse, bound, mean_diff, stderr))
+    scene.close()
+
+
+def test_queue_overflow_is_reported_not_rendered(gpu_required):
+    """A region capacity too small for the pass (forced through the test hook) must end in RT_ERR_INTERNAL, never in an image
+    with rays silently dropped."""
+    cfg, cam, b, world, _ = scene_pair("cornell.yml")
+    p = rt.render_params(128, 128, 4, cfg.max_depth, RENDER_SEED)
+    os.environ["RT_DEBUG_QUEUE_CAP"] = "1024"                       # 128 * 128 * 4 / 16 regions = 4096 rays per region
+    try:
+        scene = rt.Scene(b, world, 0)
+        with pytest.raises(rt.RtError) as e:
+            scene.render(cam, p)
+        assert e.value.code == -9 and "overflow" in str(e.value)
+        scene.close()
+    finally:
+        os.environ.pop("RT_DEBUG_QUEUE_CAP", None)
+    scene = rt.Scene(b, world, 0)
+    img, _, st = scene.render(cam, p)                               # the same call with the real capacity
+    assert st.rays > 128 * 128 * 4 and img.mean() > 0
+    scene.close()
+
+
+def test_render_multi_on_one_gpu_equals_render(gpu_required):
+    """rt_render_multi with one scene: host thread, private accumulator, the RCCL reduce (a one-rank communicator) and the
+    host add must give rt_render's image bit for bit; two handles on one GPU are refused."""
+    cfg, cam, b, world, _ = scene_pair("final_scene.yml")
+    scene = rt.Scene(b, world, 0)
+    p = rt.render_params(160, 120, 6, cfg.max_depth, RENDER_SEED, sample_offset=3)
+    want, want_sq, st = scene.render(cam, p, want_sumsq=True)
+    got, got_sq, st2 = rt.render_multi([scene], cam, p, want_sumsq=True)
+    assert st2.rays == st.rays and st2.paths == st.paths
+    assert np.array_equal(got, want) and np.array_equal(got_sq, want_sq)
+    again, _, _ = rt.render_multi([scene], cam, p, accum=got.copy())  # adds into the caller's buffer; the communicator is reused
+    assert np.array_equal(again, 2 * want)
+    twin = rt.Scene(b, world, 0)
+    with pytest.raises(rt.RtError) as e:
+        rt.render_multi([scene, twin], cam, p)
+    assert e.value.code == -1
+    twin.close(); scene.close()
+
+
+def test_render_sharded_with_the_hip_renderer(gpu_required):
+    """The per-process sharding layer (one process per GPU under torch.distributed) driving rt_render_device, at world size 1."""
+    import torch
+    from ray_tracing_amd.distributed import render_sharded
+    cfg, cam, b, world, _ = scene_pair("cornell.yml")
+    scene = rt.Scene(b, world, 0)
+    W = H = 120
+    spp = 5
+
+    def render_into(accum, first, count):
+        scene.render_device(cam, rt.render_params(W, H, count, cfg.max_depth, RENDER_SEED, sample_offset=first), accum.data_ptr(), None,
+                            torch.cuda.current_stream().cuda_stream)
+    got = render_sharded(render_into, H, W, spp, torch.device("cuda", 0)).cpu().numpy()
+    want, _, _ = scene.render(cam, rt.render_params(W, H, spp, cfg.max_depth, RENDER_SEED))
+    assert np.array_equal(got, want)
+    scene.close()

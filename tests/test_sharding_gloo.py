@@ -26,6 +26,33 @@ def test_shard_samples_partitions_the_range():
         shard_samples(10, 2, 2)
 
 
+def test_c_abi_shards_like_the_python_layer():
+    """rt_render_multi (GPUs inside one process) and render_sharded (one process per GPU) must cut the samples the same way."""
+    import ray_tracing_amd as rt
+    for total in (0, 1, 5, 16, 1000, 100001):
+        for world in (1, 2, 3, 4, 7, 8):
+            for r in range(world):
+                assert rt.shard_samples(total, r, world) == shard_samples(total, r, world)
+    for bad in ((10, 2, 2), (10, -1, 2), (-1, 0, 1), (10, 0, 0)):
+        with pytest.raises(rt.RtError) as e:
+            rt.shard_samples(*bad)
+        assert e.value.code == -1
+
+
+def test_render_multi_rejects_bad_arguments_without_a_gpu():
+    import ctypes as C
+    import ray_tracing_amd as rt
+    L = rt.lib()
+    cam = rt.make_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 20.0, 1.0, 0.0, 1.0)
+    p = rt.render_params(8, 8, 1, 5, 1)
+    buf = np.zeros((8, 8, 3), np.float32)
+    none = (C.c_void_p * 1)(None)
+    assert L.rt_render_multi(None, 1, C.byref(cam), C.byref(p), buf.ctypes.data, None, None) == -1
+    assert L.rt_render_multi(none, 0, C.byref(cam), C.byref(p), buf.ctypes.data, None, None) == -1
+    assert L.rt_render_multi(none, 1, C.byref(cam), C.byref(p), buf.ctypes.data, None, None) == -1      # null scene handle
+    assert L.rt_render_multi(none, 1, C.byref(cam), C.byref(p), None, None, None) == -1
+
+
 def _oracle_render_into(accum, first, count):
     import helpers
     cfg, cam, b, world, ob = helpers.scene_pair("cornell_box.yml")
