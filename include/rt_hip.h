@@ -174,6 +174,17 @@ int rt_render(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* a
 int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* d_accum_rgb, float* d_accum_sq,
                      void* hip_stream, RtStats* stats);
 
+/* rt_render_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
+ * that forbid hipMalloc).  It has no counterpart in the reference.  The ray queues, hit records, contribution slots and counters
+ * of a pass live in a static 64 MiB device array that every GPU the library runs on holds until the process ends, so the call
+ * makes no hipMalloc / hipFree and creates no events.  Limits: width * height <= 262144 (paths of one pass), max_depth <= 126,
+ * flags = 0 or RT_FLAG_SUMSQ; anything beyond is RT_ERR_INVALID.  With stats == NULL nothing is read back and the call returns with the work
+ * enqueued on `hip_stream`; with stats the stream is synchronised once per pass.  All calls on one GPU share that GPU's array: calls
+ * that overlap on one GPU race (serialise them on one stream).  Results are bit-identical to rt_render_device with
+ * paths_per_pass = 262144. */
+int rt_render_device_noalloc(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* d_accum_rgb, float* d_accum_sq,
+                             void* hip_stream, RtStats* stats);
+
 /* Multi-GPU render inside one process: the per-pixel sum of src/main.rs:585-589 lifted across GPUs.  scenes[i] is the same world
  * flattened onto GPU i (one handle per GPU, distinct devices).  The samples [sample_offset, sample_offset + spp) are cut into
  * n_scenes contiguous ranges (rt_shard_samples); GPU i renders its range into a private accumulator on its own host thread and

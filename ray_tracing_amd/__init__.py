@@ -102,6 +102,7 @@ API = {
     "rt_flat_destroy": (None, [_P]),
     "rt_render": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtRenderParams), _P, _P, C.POINTER(RtStats)]),
     "rt_render_device": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtRenderParams), _P, _P, _P, C.POINTER(RtStats)]),
+    "rt_render_device_noalloc": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtRenderParams), _P, _P, _P, C.POINTER(RtStats)]),
     "rt_render_multi": (C.c_int, [C.POINTER(_P), C.c_int32, C.POINTER(RtCamera), C.POINTER(RtRenderParams), _P, _P, C.POINTER(RtStats)]),
     "rt_shard_samples": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rt_trace_primary": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtRenderParams), C.c_int32, _P, _P, _P, _P, _P]),
@@ -348,6 +349,14 @@ class Scene:
         """Same, into device buffers given as raw addresses (e.g. torch.Tensor.data_ptr())."""
         st = RtStats()
         _check(lib().rt_render_device(self._h, C.byref(cam), C.byref(params), accum_ptr, sumsq_ptr, stream, C.byref(st)))
+        return st
+
+    def render_device_noalloc(self, cam, params, accum_ptr, sumsq_ptr=None, stream=None, want_stats=True):
+        """rt_render_device_noalloc: the same render out of the library's static device workspace (no device allocation).
+        With want_stats=False nothing is read back and the call returns with the work enqueued on `stream`."""
+        st = RtStats() if want_stats else None
+        _check(lib().rt_render_device_noalloc(self._h, C.byref(cam), C.byref(params), accum_ptr, sumsq_ptr, stream,
+                                              C.byref(st) if want_stats else None))
         return st
 
     def trace_primary(self, cam, params, sample=0, want_normal=False, want_uv=False):

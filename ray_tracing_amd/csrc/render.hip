@@ -662,9 +662,27 @@ __global__ __launch_bounds__(RT_BLOCK) void k_scatter_rays(RtSceneView sc, const
     w[7] = sf.p.x; w[8] = sf.p.y; w[9] = sf.p.z; w[10] = dir.x; w[11] = dir.y; w[12] = dir.z; w[13] = time;
 }
 
+// ------------------------------------------------------------------ static scratch of rt_render_device_noalloc
+// A fixed workspace for callers that cannot allocate device memory (HIP graph capture, serving loops): passes of at most
+// RT_NOALLOC_MAX_PATHS paths and RT_NOALLOC_MAX_DEPTH bounces.  Every GPU the library runs on holds its own copy of the array
+// until the process ends.  In host code the array's NAME is only a handle for hipGetSymbolAddress: the address that kernels
+// and memsets take is the per-device pointer that call returns (RtScene::static_scratch).
+#define RT_NOALLOC_MAX_PATHS (1u << 18)
+#define RT_NOALLOC_MAX_DEPTH 126
+static constexpr size_t kNaRows = RT_NOALLOC_MAX_DEPTH + 2;
+static constexpr size_t kNaCap = ((RT_NOALLOC_MAX_PATHS + RT_SHARDS - 1) / RT_SHARDS + (size_t)1024 * (RT_SHARDS + 2) + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK;
+static constexpr size_t kNaCountsBytes = 2 * kNaRows * RT_SHARDS * RT_COUNT_STRIDE * sizeof(uint32_t);
+static constexpr size_t kNaFoldedBytes = (kNaRows * sizeof(unsigned long long) + 255) / 256 * 256;
+static constexpr size_t kNaContribBytes = (size_t)RT_NOALLOC_MAX_PATHS * sizeof(rt_f4);
+static constexpr size_t kNaStreamBytes = kNaCap * RT_SHARDS * sizeof(rt_f4);     // one queue stream, or the hit stream
+static constexpr size_t kNaScratchBytes = kNaCountsBytes + kNaFoldedBytes + kNaContribBytes + 7 * kNaStreamBytes;   // 64 MiB
+static_assert(kNaCountsBytes % 256 == 0 && kNaContribBytes % 256 == 0 && kNaStreamBytes % 256 == 0, "pieces of the scratch array stay 256-byte aligned");
+static __device__ __align__(256) unsigned char g_noalloc_scratch[kNaScratchBytes];
+
 // ------------------------------------------------------------------ host side
 // Device memory of one wavefront pass: the two ray queues (three float4 streams each), the hit stream, one contribution slot
-// per path and the counters.  A scene owns a grow-only one (hipMalloc).
+// per path and the counters.  A scene owns a grow-only one (hipMalloc); rt_render_device_noalloc carves a fixed one out of a
+// static device array instead.
 struct Workspace {
     size_t paths = 0, cap = 0;             // paths it was sized for; slots per queue region
     rt_f4 *qa[2] = {nullptr, nullptr}, *qb[2] = {nullptr, nullptr}, *qc[2] = {nullptr, nullptr}, *contrib = nullptr, *hits = nullptr;
@@ -682,6 +700,7 @@ struct RtScene {
     std::vector<void*> allocs;     // scene arrays
     uint64_t device_bytes = 0;
     Workspace ws;                          // render workspace (grow-only)
+    unsigned char* static_scratch = nullptr;   // this device's copy of the static scratch array (rt_render_device_noalloc)
     RtTracePlan plan;                      // k_trace: what lives in the block's LDS
     int lds_bytes = 0;                     // k_trace: dynamic LDS size
     unsigned trace_gx = 1;                 // k_trace: blocks per region
@@ -883,6 +902,20 @@ static int ensure_workspace(RtScene* s, size_t n_paths) {
     w.paths = n_paths; w.cap = cap;
     return RT_OK;
 }
+// The fixed workspace inside this device's copy of the static scratch array.
+static Workspace static_workspace(unsigned char* base) {
+    Workspace w;
+    unsigned char* p = base;
+    auto take = [&](size_t bytes) { unsigned char* r = p; p += bytes; return r; };
+    w.counts = (uint32_t*)take(kNaCountsBytes);
+    w.folded = (unsigned long long*)take(kNaFoldedBytes);
+    w.contrib = (rt_f4*)take(kNaContribBytes);
+    for (int i = 0; i < 2; ++i) { w.qa[i] = (rt_f4*)take(kNaStreamBytes); w.qb[i] = (rt_f4*)take(kNaStreamBytes); w.qc[i] = (rt_f4*)take(kNaStreamBytes); }
+    w.hits = (rt_f4*)take(kNaStreamBytes);
+    w.rows = (int)kNaRows; w.paths = RT_NOALLOC_MAX_PATHS; w.cap = kNaCap; w.work = nullptr;
+    return w;
+}
+
 static int check_common(const RtScene* s, const RtCamera* cam, const RtRenderParams* p) {
     if (!s || !cam || !p) return rt_set_error(RT_ERR_INVALID, "null argument");
     if (p->width < 2 || p->height < 2) return rt_set_error(RT_ERR_INVALID, "width and height must be >= 2 (main.rs:572-573 divides by W-1, H-1)");
@@ -942,6 +975,8 @@ int rt_scene_create_ex(const RtBuilder* b, RtObj world, int device, int flags, R
     int rc = [&]() -> int {
         HIP_TRY(hipSetDevice(device));
         HIP_TRY(hipDeviceGetAttribute(&s->n_cu, hipDeviceAttributeMultiprocessorCount, device));
+        // this device's copy of the static scratch array (the device is current): the address kernels and memsets take
+        HIP_TRY(hipGetSymbolAddress((void**)&s->static_scratch, HIP_SYMBOL(g_noalloc_scratch)));
         rt::FlatScene& f = s->flat;
         if (!f.tlas_items.empty()) {
             // Deferred top level: its nodes are built on the GPU behind the bottom-level nodes, then copied back so that the
@@ -1205,6 +1240,38 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     std::vector<unsigned long long> h_folded((size_t)p->max_depth + 2);
     float* sq = (p->flags & RT_FLAG_SUMSQ) ? d_accum_sq : nullptr;
     rc = render_passes(s, s->ws, cam, p, chunk_max, d_accum, sq, st, true, h_folded.data(), local);
+    if (rc) return rc;
+    local.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    if (stats) *stats = local;
+    return RT_OK;
+}
+
+int rt_render_device_noalloc(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* d_accum, float* d_accum_sq, void* hip_stream, RtStats* stats) {
+    int rc = check_common(s, cam, p);
+    if (rc) return rc;
+    if (!d_accum) return rt_set_error(RT_ERR_INVALID, "null accumulation buffer");
+    if (p->spp < 0) return rt_set_error(RT_ERR_INVALID, "spp must be >= 0");
+    if ((p->flags & RT_FLAG_SUMSQ) && !d_accum_sq) return rt_set_error(RT_ERR_INVALID, "RT_FLAG_SUMSQ needs accum_sq");
+    if (p->flags & ~RT_FLAG_SUMSQ) return rt_set_error(RT_ERR_INVALID, "rt_render_device_noalloc: only RT_FLAG_SUMSQ is supported (counters and timing need allocations)");
+    const size_t n_pixels = (size_t)p->width * (size_t)p->height;
+    if (n_pixels > RT_NOALLOC_MAX_PATHS)
+        return rt_set_error(RT_ERR_INVALID, "rt_render_device_noalloc: width * height = " + std::to_string(n_pixels) + " exceeds the static workspace of " +
+                                                std::to_string(RT_NOALLOC_MAX_PATHS) + " paths per pass; use rt_render_device");
+    if (p->max_depth > RT_NOALLOC_MAX_DEPTH)
+        return rt_set_error(RT_ERR_INVALID, "rt_render_device_noalloc: max_depth exceeds " + std::to_string(RT_NOALLOC_MAX_DEPTH) + "; use rt_render_device");
+    if (!s->static_scratch) return rt_set_error(RT_ERR_INTERNAL, "the static scratch array was not resolved for this device");
+    hipStream_t st = (hipStream_t)hip_stream;
+    HIP_TRY(hipSetDevice(s->device));
+    auto t_begin = std::chrono::steady_clock::now();
+    size_t target = p->paths_per_pass > 0 ? std::min<size_t>((size_t)p->paths_per_pass, RT_NOALLOC_MAX_PATHS) : (size_t)RT_NOALLOC_MAX_PATHS;
+    int chunk_max = (int)std::max<size_t>(1, target / n_pixels);
+    chunk_max = std::min(chunk_max, std::max(1, p->spp));
+    const Workspace ws = static_workspace(s->static_scratch);
+    RtStats local; std::memset(&local, 0, sizeof(local));
+    local.paths = (uint64_t)n_pixels * (uint64_t)p->spp;
+    unsigned long long h_folded[RT_NOALLOC_MAX_DEPTH + 2];
+    float* sq = (p->flags & RT_FLAG_SUMSQ) ? d_accum_sq : nullptr;
+    rc = render_passes(s, ws, cam, p, chunk_max, d_accum, sq, st, false, stats ? h_folded : nullptr, local);
     if (rc) return rc;
     local.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     if (stats) *stats = local;

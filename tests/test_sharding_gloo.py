@@ -51,6 +51,7 @@ def test_render_multi_rejects_bad_arguments_without_a_gpu():
     assert L.rt_render_multi(none, 0, C.byref(cam), C.byref(p), buf.ctypes.data, None, None) == -1
     assert L.rt_render_multi(none, 1, C.byref(cam), C.byref(p), buf.ctypes.data, None, None) == -1      # null scene handle
     assert L.rt_render_multi(none, 1, C.byref(cam), C.byref(p), None, None, None) == -1
+    assert L.rt_render_device_noalloc(None, C.byref(cam), C.byref(p), buf.ctypes.data, None, None, None) == -1
 
 
 def _oracle_render_into(accum, first, count):
