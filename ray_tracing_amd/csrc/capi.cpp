@@ -115,6 +115,7 @@ int rt_flat_create_ex(const RtBuilder* b, RtObj world, int flags, RtFlat** out) 
     bool ok = rt::flatten(b->b, world, f->flat, err, (flags & RT_BVH_LINEAR) != 0);
     if (ok && !f->flat.tlas_items.empty()) ok = rt::lbvh_finish_host(f->flat, err);
     if (!ok) { delete f; return rt_set_error(rt_status_of(err), err); }
+    rt::build_wide_bvh(f->flat);
     f->view = f->flat.view();
     *out = f;
     return RT_OK;

@@ -478,6 +478,7 @@ RtSceneView FlatScene::view() const {
     v.n_media = (int)media.size() / RT_MEDIUM_F4; v.n_materials = (int)materials.size() / RT_MATERIAL_F4;
     v.n_textures = (int)textures.size() / RT_TEXTURE_F4; v.n_perlin = (int)perlin_vec.size() / RT_PERLIN_VEC_F4;
     v.max_stack = max_stack; v.n_boxes = (int)boxes.size() / 2;
+    v.wnodes = wnodes.data(); v.winst_roots = winst_roots.data(); v.n_wnodes = (int)wnodes.size() / 4; v.wroot = wroot; v.wmax_stack = wmax_stack;
     return v;
 }
 

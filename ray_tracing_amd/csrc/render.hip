@@ -38,6 +38,12 @@
 #ifndef RT_NODE_LEAVE_RATIO
 #define RT_NODE_LEAVE_RATIO 2
 #endif
+#ifndef RT_NODE_LEAVE_RATIO_WIDE   /* the same vote for 4-wide nodes, whose steps are twice as long: leave earlier */
+#define RT_NODE_LEAVE_RATIO_WIDE 1
+#endif
+#ifndef RT_NODE_LEAVE_DEN_WIDE
+#define RT_NODE_LEAVE_DEN_WIDE 1
+#endif
 #ifndef RT_LEAF_LEAVE_RATIO
 #define RT_LEAF_LEAVE_RATIO 1
 #endif
@@ -101,6 +107,7 @@ struct RtTracePlan {
     int32_t wide_stack;                                                   // 1: 32-bit entries, 0: 16-bit entries (TraceStack)
     int32_t resident;                                                     // 1: all nodes and all primitive arrays are in LDS
     int32_t refill_lanes;                                                 // idle lanes of a wave that trigger a refill
+    int32_t wide4;                                                        // 1: the nodes are the 4-wide quantised tree (sc.wnodes)
 };
 
 typedef float __attribute__((ext_vector_type(4))) rt_vf4;
@@ -111,8 +118,9 @@ __device__ __forceinline__ rt_f4 lds_ld4(lds_f4* p) { rt_vf4 v = *p; rt_f4 r; r.
 // RESIDENT = the whole node array and every primitive array are in LDS: the accessors then have no global-memory path at
 // all, which matters beyond the saved branch -- with no other VMEM load in the traversal loop the compiler has no reason
 // to wait on vmcnt there, so the prefetch of the next ray batch really stays in flight.
-template <bool RESIDENT> struct TraceNodes {   // node records: [first, first + n_lds) (the top of the tree) from LDS, the rest from global memory
-    const rt_f4* global; lds_f4* lds; int32_t n_lds, first;
+template <bool RESIDENT, bool WIDE4> struct TraceNodes {   // node records: [first, first + n_lds) (the top of the tree) from LDS, the rest from global memory
+    static constexpr bool kWide = WIDE4;                       // WIDE4: the records are 4-wide quantised nodes (sc.wnodes)
+    const rt_f4* global; lds_f4* lds; int32_t n_lds, first; const int32_t* inst_roots;
     __device__ __forceinline__ void get(int32_t n, rt_f4 q[4]) const {
         if (RESIDENT || (uint32_t)(n - first) < (uint32_t)n_lds) {
             lds_f4* p = lds + 4 * (RESIDENT ? n : n - first);
@@ -122,6 +130,8 @@ template <bool RESIDENT> struct TraceNodes {   // node records: [first, first + 
             q[0] = ld4(p); q[1] = ld4(p + 1); q[2] = ld4(p + 2); q[3] = ld4(p + 3);
         }
     }
+    __device__ __forceinline__ int32_t root(const RtSceneView& sc) const { return WIDE4 ? sc.wroot : sc.root; }
+    __device__ __forceinline__ int32_t instance_root(int32_t i, int32_t binary_root) const { return WIDE4 ? inst_roots[i] : binary_root; }
 };
 template <bool RESIDENT> struct TracePrims {   // primitive records: every array is either wholly in LDS (offset >= 0) or read from global memory
     const RtSceneView* sc; lds_f4* lds; int32_t o_sph, o_msph, o_rect, o_box, o_inst;
@@ -174,7 +184,7 @@ template <> __device__ __forceinline__ TraceStack<false> make_stack<false>(unsig
 // A lane that has finished its ray waits until `refill_lanes` lanes of its wave are idle; the idle lanes then take the
 // next rays of the region through one wave-aggregated atomic on the region's cursor (ballot + mbcnt ranks).  A wave
 // therefore never drains to a few long rays, which is what a ray-per-thread launch costs on 64-wide waves.
-template <bool STATS, int TB, bool WIDE, bool RESIDENT>
+template <bool STATS, int TB, bool WIDE, bool RESIDENT, bool WIDE4>
 __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, uint32_t cap, const uint32_t* counts_in, uint32_t* cursors,
                                               const rt_f4* ia, const rt_f4* ib, rt_f4* hits, unsigned long long* work) {
     const uint32_t region = blockIdx.y;
@@ -183,7 +193,8 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, 
     extern __shared__ __align__(16) unsigned char smem[];
     {   // scene -> LDS
         rt_f4* dst = reinterpret_cast<rt_f4*>(smem);
-        for (int i = threadIdx.x; i < plan.n_nodes_lds * 4; i += TB) dst[i] = ld4(sc.nodes + 4 * (size_t)plan.first_lds + i);
+        const rt_f4* node_src = WIDE4 ? sc.wnodes : sc.nodes;
+        for (int i = threadIdx.x; i < plan.n_nodes_lds * 4; i += TB) dst[i] = ld4(node_src + 4 * (size_t)plan.first_lds + i);
         if (plan.off_spheres >= 0) for (int i = threadIdx.x; i < sc.n_spheres; i += TB) dst[plan.off_spheres + i] = ld4(sc.spheres + i);
         if (plan.off_mspheres >= 0) for (int i = threadIdx.x; i < sc.n_mspheres * 3; i += TB) dst[plan.off_mspheres + i] = ld4(sc.mspheres + i);
         if (plan.off_rects >= 0) for (int i = threadIdx.x; i < sc.n_rects * 2; i += TB) dst[plan.off_rects + i] = ld4(sc.rects + i);
@@ -192,7 +203,8 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, 
     }
     __syncthreads();
     lds_f4* lds = (lds_f4*)smem;
-    TraceNodes<RESIDENT> nodes; nodes.global = sc.nodes; nodes.lds = lds; nodes.n_lds = plan.n_nodes_lds; nodes.first = plan.first_lds;
+    TraceNodes<RESIDENT, WIDE4> nodes; nodes.global = WIDE4 ? sc.wnodes : sc.nodes; nodes.lds = lds; nodes.n_lds = plan.n_nodes_lds; nodes.first = plan.first_lds;
+    nodes.inst_roots = sc.winst_roots;
     TracePrims<RESIDENT> prims; prims.sc = &sc; prims.lds = lds;
     prims.o_sph = plan.off_spheres; prims.o_msph = plan.off_mspheres; prims.o_rect = plan.off_rects; prims.o_box = plan.off_boxes; prims.o_inst = plan.off_instances;
     TraceStack<WIDE> stk = make_stack<WIDE>(smem, plan.off_stack, plan.stack_cap, TB);
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, 
     float time = 0.0f;
     RtTrav tv; tv.o = wo; tv.d = wd; tv.inv = wd; tv.inst = -1; tv.sp = 0; tv.cur = RT_EMPTY_STACK;
     RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
-    RtCounters cnt = {0, 0, 0, 0, 0, 0};
+    RtCounters cnt = {0, 0, 0, 0, 0, 0, 0};
     uint32_t dbg[4] = {0, 0, 0, 0};   // STATS: wave-level counts of outer iterations, refills, node-loop and leaf-loop iterations
 
     for (;;) {
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, 
                     wo = mk3(a.x, a.y, a.z); wd = mk3(b.x, b.y, b.z); time = a.w; src = (uint32_t)f2i(b.w);
                     slot = idx; active = true;
                     hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
-                    rt_trav_begin(sc, wo, wd, tv);
+                    rt_trav_begin(sc, nodes, wo, wd, tv);
                 }
             }
             if (base + (uint32_t)n_idle >= n) exhausted = true;
@@ -242,8 +254,9 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, 
             const int n_enter = __popcll(__ballot(rt_is_inner(tv.cur)));
             while (rt_is_inner(tv.cur)) {
                 if (STATS) { unsigned long long ex = __ballot(true); if ((int)lane == __ffsll((long long)ex) - 1) dbg[2]++; }
-                rt_node_step<STATS>(nodes, tv, RT_TMIN, hit, stk, &cnt);
-                { int n_in = __popcll(__ballot(rt_is_inner(tv.cur))); if (n_in * RT_NODE_LEAVE_RATIO < n_enter - n_in) break; }
+                rt_inner_step<STATS>(nodes, tv, RT_TMIN, hit, stk, &cnt);
+                { int n_in = __popcll(__ballot(rt_is_inner(tv.cur)));
+                  if (WIDE4 ? (n_in * RT_NODE_LEAVE_RATIO_WIDE < (n_enter - n_in) * RT_NODE_LEAVE_DEN_WIDE) : (n_in * RT_NODE_LEAVE_RATIO < n_enter - n_in)) break; }
             }
             if (tv.cur >= 0) {
                 if (tv.cur == RT_SENTINEL) rt_sentinel_step(wo, wd, tv, stk);
@@ -253,11 +266,11 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, 
                     if (STATS) { unsigned long long ex = __ballot(true); if ((int)lane == __ffsll((long long)ex) - 1) dbg[3]++; }
 #ifdef RT_LEAF_TWICE   /* timing experiment: the leaf step run twice with the same result */
                     { RtTrav t2 = tv; RtHit h2 = hit;
-                      rt_leaf_step<false>(prims, wo, wd, time, RT_TMIN, src, t2, h2, stk, &cnt);
+                      rt_leaf_step<false>(nodes, prims, wo, wd, time, RT_TMIN, src, t2, h2, stk, &cnt);
                       asm volatile("" : "+v"(wo.x), "+v"(wd.x), "+v"(h2.t));
                       if (h2.t < 0.0f) hit.t = h2.t; }
 #endif
-                    rt_leaf_step<STATS>(prims, wo, wd, time, RT_TMIN, src, tv, hit, stk, &cnt);
+                    rt_leaf_step<STATS>(nodes, prims, wo, wd, time, RT_TMIN, src, tv, hit, stk, &cnt);
                     { int n_lf = __popcll(__ballot(tv.cur < 0)); if (n_lf * RT_LEAF_LEAVE_RATIO < n_leaf_enter - n_lf) break; }
                 } while (tv.cur < 0);
             }
@@ -271,6 +284,7 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, 
         atomicAdd(work + 0, (unsigned long long)cnt.nodes); atomicAdd(work + 1, (unsigned long long)cnt.spheres);
         atomicAdd(work + 2, (unsigned long long)cnt.mspheres); atomicAdd(work + 3, (unsigned long long)cnt.rects);
         atomicAdd(work + 4, (unsigned long long)cnt.instances); atomicAdd(work + 7, (unsigned long long)cnt.boxes);
+        if (WIDE4) atomicAdd(work + 15, (unsigned long long)cnt.wnodes);
         for (int k = 0; k < 4; ++k) if (dbg[k]) atomicAdd(work + 16 + k, (unsigned long long)dbg[k]);
     }
 }
@@ -446,6 +460,9 @@ typedef __attribute__((address_space(3))) const rt_vi2 lds_i2;
 typedef __attribute__((address_space(3))) const unsigned char lds_u8;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct ShadeTables {   // every table from the block's LDS copy
+    static constexpr bool kWide = false;   // as a Nodes source (FUSED): binary nodes
+    __device__ __forceinline__ int32_t root(const RtSceneView& sc) const { return sc.root; }
+    __device__ __forceinline__ int32_t instance_root(int32_t, int32_t binary_root) const { return binary_root; }
     lds_f4* lds; RtShadePlan pl;
     __device__ __forceinline__ void pair(int32_t off, uint32_t i, rt_f4& r0, rt_f4& r1) const { lds_f4* m = lds + off + 2 * i; r0 = lds_ld4(m); r1 = lds_ld4(m + 1); }
     __device__ __forceinline__ rt_i2 meta(int32_t off, uint32_t i) const { rt_vi2 v = ((lds_i2*)(lds + off))[i]; rt_i2 r; r.x = v.x; r.y = v.y; return r; }
@@ -725,34 +742,39 @@ static const int kLdsBudget = 160 * 1024 - 512;   // dynamic LDS a 1024-thread b
 static void launch_trace(RtScene* s, const Workspace& ws, bool stats, hipStream_t st, uint32_t cap, const uint32_t* cin, uint32_t* cursors,
                          const rt_f4* qa, const rt_f4* qb) {
     dim3 grid(s->trace_gx, RT_SHARDS);
-#define RT_LAUNCH_TRACE(TB_, WIDE_, RES_)                                                                                     \
+#define RT_LAUNCH_TRACE(TB_, WIDE_, RES_, W4_)                                                                                \
     do {                                                                                                                      \
-        if (stats) hipLaunchKernelGGL((k_trace<true, TB_, WIDE_, RES_>), grid, dim3(TB_), (size_t)s->lds_bytes, st, s->view, s->plan, cap, \
+        if (stats) hipLaunchKernelGGL((k_trace<true, TB_, WIDE_, RES_, W4_>), grid, dim3(TB_), (size_t)s->lds_bytes, st, s->view, s->plan, cap, \
                                       cin, cursors, qa, qb, ws.hits, ws.work);                                                \
-        else hipLaunchKernelGGL((k_trace<false, TB_, WIDE_, RES_>), grid, dim3(TB_), (size_t)s->lds_bytes, st, s->view, s->plan, cap,      \
+        else hipLaunchKernelGGL((k_trace<false, TB_, WIDE_, RES_, W4_>), grid, dim3(TB_), (size_t)s->lds_bytes, st, s->view, s->plan, cap,      \
                                 cin, cursors, qa, qb, ws.hits, ws.work);                                                      \
     } while (0)
-    if (s->trace_block == 1024 && s->plan.resident) RT_LAUNCH_TRACE(1024, false, true);
-    else if (s->trace_block == 1024 && !s->plan.wide_stack) RT_LAUNCH_TRACE(1024, false, false);
-    else if (s->trace_block == 1024) RT_LAUNCH_TRACE(1024, true, false);
-    else RT_LAUNCH_TRACE(256, true, false);
+    if (s->plan.wide4 && s->plan.resident) RT_LAUNCH_TRACE(1024, true, true, true);
+    else if (s->plan.wide4) RT_LAUNCH_TRACE(1024, true, false, true);
+    else if (s->trace_block == 1024 && s->plan.resident) RT_LAUNCH_TRACE(1024, false, true, false);
+    else if (s->trace_block == 1024 && !s->plan.wide_stack) RT_LAUNCH_TRACE(1024, false, false, false);
+    else if (s->trace_block == 1024) RT_LAUNCH_TRACE(1024, true, false, false);
+    else RT_LAUNCH_TRACE(256, true, false, false);
 #undef RT_LAUNCH_TRACE
 }
 
 // Fills the LDS of a k_trace block of `threads` threads within `budget` bytes.  The stack always has the full depth the
 // BVH can need.  If the whole node array fits beside a stack of 16-bit entries (and node indices fit 15 bits), that form
 // is used and the room left goes to whole primitive arrays; otherwise 32-bit entries and a breadth-first node prefix.
-static void fill_plan(const RtSceneView& v, int max_stack, int threads, int budget, int refill_lanes, bool allow_narrow, int top_first,
-                      RtTracePlan& pl, int& lds_bytes) {
+// wide4: the plan is for the 4-wide tree (n_nodes of sc.wnodes): 32-bit stack entries always, and when all nodes fit, primitive
+// arrays beside them as in the narrow form.
+static void fill_plan(const RtSceneView& v, int n_nodes, int max_stack, int threads, int budget, int refill_lanes, bool allow_narrow, bool wide4,
+                      int top_first, RtTracePlan& pl, int& lds_bytes) {
     const int stack_cap = std::max(1, max_stack);
-    pl.stack_cap = stack_cap; pl.refill_lanes = refill_lanes; pl.resident = 0; pl.first_lds = 0;
+    pl.stack_cap = stack_cap; pl.refill_lanes = refill_lanes; pl.resident = 0; pl.first_lds = 0; pl.wide4 = wide4 ? 1 : 0;
     pl.off_spheres = pl.off_mspheres = pl.off_rects = pl.off_boxes = pl.off_instances = -1;
     const int narrow = stack_cap * threads * 2, wide = stack_cap * threads * 4;
+    const int stack_bytes = wide4 ? wide : narrow;
     int used;
-    if (allow_narrow && v.n_nodes > 0 && v.n_nodes <= 32767 && v.n_nodes * 64 + narrow <= budget) {
-        pl.wide_stack = 0; pl.n_nodes_lds = v.n_nodes;
-        used = v.n_nodes * 64;
-        int room = budget - used - narrow;
+    if (n_nodes > 0 && (wide4 || (allow_narrow && n_nodes <= 32767)) && n_nodes * 64 + stack_bytes <= budget) {
+        pl.wide_stack = wide4 ? 1 : 0; pl.n_nodes_lds = n_nodes;
+        used = n_nodes * 64;
+        int room = budget - used - stack_bytes;
         auto place = [&](int n_records, int32_t& off) {
             if (n_records > 0 && n_records * 16 <= room) { off = used / 16; used += n_records * 16; room -= n_records * 16; }
         };
@@ -765,11 +787,11 @@ static void fill_plan(const RtSceneView& v, int max_stack, int threads, int budg
                       (v.n_instances == 0 || pl.off_instances >= 0) && (v.n_rects == 0 || pl.off_rects >= 0) &&
                       (v.n_mspheres == 0 || pl.off_mspheres >= 0);
         pl.off_stack = used / 16;
-        lds_bytes = used + narrow;
+        lds_bytes = used + stack_bytes;
     } else {
         pl.wide_stack = 1;
         pl.first_lds = top_first;
-        pl.n_nodes_lds = std::max(0, std::min(v.n_nodes - top_first, (budget - wide) / 64));
+        pl.n_nodes_lds = std::max(0, std::min(n_nodes - top_first, (budget - wide) / 64));
         used = pl.n_nodes_lds * 64;
         pl.off_stack = used / 16;
         lds_bytes = used + wide;
@@ -786,11 +808,19 @@ static int plan_trace(RtScene* s) {
     int blocks_per_cu = 1;
     bool planned = false;
     if (want == 1024 && s->flat.max_stack * 1024 * 4 + 64 <= kLdsBudget) {
-        fill_plan(s->view, s->flat.max_stack, 1024, kLdsBudget, refill, narrow_ok, s->top_first, s->plan, s->lds_bytes);
+        fill_plan(s->view, s->view.n_nodes, s->flat.max_stack, 1024, kLdsBudget, refill, narrow_ok, false, s->top_first, s->plan, s->lds_bytes);
+        // The 4-wide quantised tree replaces the binary one when the binary node array does not fit the LDS (a ray then makes
+        // half as many dependent fetches from L2 / HBM), provided its deeper stack fits.  RT_TRACE_BVH4 = 1 / 0 forces the choice.
+        bool want_wide = !s->plan.resident && s->plan.wide_stack;
+        if (const char* e = std::getenv("RT_TRACE_BVH4")) want_wide = std::atoi(e) != 0;
+        if (want_wide && s->view.n_wnodes > 0 && s->view.wmax_stack * 1024 * 4 + 64 <= kLdsBudget)
+            fill_plan(s->view, s->view.n_wnodes, s->view.wmax_stack, 1024, kLdsBudget, refill, false, true, 0, s->plan, s->lds_bytes);
         const void* fns[2];
-        if (s->plan.resident) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, false, true>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, false, true>); }
-        else if (!s->plan.wide_stack) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, false, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, false, false>); }
-        else { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, false>); }
+        if (s->plan.wide4 && s->plan.resident) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, true, true>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, true, true>); }
+        else if (s->plan.wide4) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, false, true>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, false, true>); }
+        else if (s->plan.resident) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, false, true, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, false, true, false>); }
+        else if (!s->plan.wide_stack) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, false, false, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, false, false, false>); }
+        else { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, false, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, false, false>); }
         // the limit is a property of the kernel, not of this scene: always the whole budget, so that a scene created
         // later with a smaller plan does not lower it for this one
         hipError_t e = hipFuncSetAttribute(fns[0], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
@@ -799,11 +829,11 @@ static int plan_trace(RtScene* s) {
         else (void)hipGetLastError();   // this device does not give one workgroup that much LDS: use the small blocks
     }
     if (!planned) {
-        fill_plan(s->view, s->flat.max_stack, 256, 40 * 1024 - 128, refill, false, s->top_first, s->plan, s->lds_bytes);
+        fill_plan(s->view, s->view.n_nodes, s->flat.max_stack, 256, 40 * 1024 - 128, refill, false, false, s->top_first, s->plan, s->lds_bytes);
         s->trace_block = 256; blocks_per_cu = 4;
         if (s->lds_bytes > 48 * 1024) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, 256, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, 256, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, 256, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, 256, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
         }
     }
     s->trace_gx = (unsigned)std::max(1, (std::max(1, s->n_cu) * blocks_per_cu + RT_SHARDS - 1) / RT_SHARDS);
@@ -1032,8 +1062,11 @@ int rt_scene_create_ex(const RtBuilder* b, RtObj world, int device, int flags, R
             }
             s->nodes_on_device = d_nodes;
         }
+        rt::build_wide_bvh(f);
         RtSceneView v = f.view();
         int r;
+        if ((r = upload(s, f.wnodes, &v.wnodes))) return r;
+        if ((r = upload(s, f.winst_roots, &v.winst_roots))) return r;
         if (s->nodes_on_device) v.nodes = s->nodes_on_device;
         else if ((r = upload(s, f.nodes, &v.nodes))) return r;
         if ((r = upload(s, f.spheres, &v.spheres))) return r;

@@ -171,14 +171,16 @@ RT_HD void rt_camera_ray(const RtCameraDev& cam, const RtFrameDev& fr, uint32_t 
 RT_HD bool rt_sphere_roots(v3 c, float r, v3 o, v3 d, float& tn, float& tf) {
     // The cancelling terms of objects.rs:206-210 (oc = o - c, c = |oc|^2 - r^2, discriminant) are formed in f64:
     // in fp32 they lose all digits for the r = 1000 ground spheres seen from 3 units above, and for every
-    // grazing hit.  gfx950 issues f64 FMAs at the fp32 FMA rate, and doing it always (instead of only when
+    // grazing hit.  gfx950 issues f64 FMAs at close to the fp32 FMA rate, and doing it always (instead of only when
     // fp32 would fail) keeps the 64 lanes of a wave on one code path.
     double fx = (double)o.x - (double)c.x, fy = (double)o.y - (double)c.y, fz = (double)o.z - (double)c.z;
     double dx = d.x, dy = d.y, dz = d.z, rr = r;
-    double A = dx * dx + dy * dy + dz * dz;
-    double B = -(fx * dx + fy * dy + fz * dz);
-    double Cc = fx * fx + fy * fy + fz * fz - rr * rr;
-    double D = B * B - A * Cc;
+    // explicit fused multiply-adds: the file is compiled with -ffp-contract=off (so that the host build of these functions
+    // rounds like the device), and the plain expressions would issue 26 f64 instructions where these issue 15
+    double A = fma(dx, dx, fma(dy, dy, dz * dz));
+    double B = -fma(fx, dx, fma(fy, dy, fz * dz));
+    double Cc = fma(fx, fx, fma(fy, fy, fma(fz, fz, -(rr * rr))));
+    double D = fma(B, B, -(A * Cc));
     if (!(D >= 0.0)) return false;
     float a = (float)A, bp = (float)B, cc = (float)Cc;
     float q = bp + copysignf(rt_sqrt((float)D), bp);
@@ -273,7 +275,7 @@ RT_HD v3 rt_to_object_dir(rt_f4 i0, v3 d) {
 struct RtHit { float t; uint32_t code; int32_t inst; };
 
 // Work counters of an instrumented build (STATS = true); the normal kernels compile them away.
-struct RtCounters { uint32_t nodes, spheres, mspheres, rects, instances, boxes; };
+struct RtCounters { uint32_t nodes, spheres, mspheres, rects, instances, boxes, wnodes; };
 
 // ------------------------------------------------------------------ closest surface hit
 // Stack-based traversal of the two-level BVH; equivalent to bvh.rs:159-187 + objects.rs:67-78
@@ -290,12 +292,28 @@ RT_HD void rt_trav_ray(RtTrav& tv, v3 o, v3 d) {
     tv.o = o; tv.d = d; tv.inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
 }
 
+// A Nodes source: get(node, q[4]) fetches the 64-byte record of an inner node; kWide tells which layout the records have
+// (false: binary node of rt_types.h, true: 4-wide quantised node of wide_bvh.cpp); root(sc) = the top-level root;
+// instance_root(i, r) = the root of instance i's subtree, r being the binary tree's root stored in the instance record.
 struct RtGlobalNodes {
+    static constexpr bool kWide = false;
     const rt_f4* nodes;
     RT_HDM void get(int32_t n, rt_f4 q[4]) const {
         const rt_f4* p = nodes + 4 * (size_t)n;
         q[0] = ld4(p); q[1] = ld4(p + 1); q[2] = ld4(p + 2); q[3] = ld4(p + 3);
     }
+    RT_HDM int32_t root(const RtSceneView& sc) const { return sc.root; }
+    RT_HDM int32_t instance_root(int32_t, int32_t binary_root) const { return binary_root; }
+};
+struct RtGlobalWideNodes {
+    static constexpr bool kWide = true;
+    const rt_f4* nodes; const int32_t* inst_roots;
+    RT_HDM void get(int32_t n, rt_f4 q[4]) const {
+        const rt_f4* p = nodes + 4 * (size_t)n;
+        q[0] = ld4(p); q[1] = ld4(p + 1); q[2] = ld4(p + 2); q[3] = ld4(p + 3);
+    }
+    RT_HDM int32_t root(const RtSceneView& sc) const { return sc.wroot; }
+    RT_HDM int32_t instance_root(int32_t i, int32_t) const { return inst_roots[i]; }
 };
 
 // Primitive records as the leaf step fetches them.  This one reads the scene's global arrays; the closest-hit kernel
@@ -330,9 +348,11 @@ struct RtGlobalTables : RtGlobalPrims {
 
 RT_HD bool rt_is_inner(int32_t cur) { return (uint32_t)cur < (uint32_t)RT_SENTINEL; }
 
-RT_HD void rt_trav_begin(const RtSceneView& sc, v3 wo, v3 wd, RtTrav& tv) {
+template <class Nodes>
+RT_HD void rt_trav_begin(const RtSceneView& sc, const Nodes& nodes, v3 wo, v3 wd, RtTrav& tv) {
     rt_trav_ray(tv, wo, wd);
-    tv.inst = -1; tv.sp = 0; tv.cur = sc.root < 0 ? RT_EMPTY_STACK : sc.root;
+    const int32_t root = nodes.root(sc);
+    tv.inst = -1; tv.sp = 0; tv.cur = root < 0 ? RT_EMPTY_STACK : root;
 }
 // A Stack holds the postponed children of one ray.  put(i, node, which, code): entry i = child `which` (0 left, 1 right) of
 // inner node `node`, whose child code is `code` (a stack may keep either form); put_sentinel(i); take(i) returns the
@@ -358,6 +378,52 @@ RT_HD void rt_node_step(const Nodes& nodes, RtTrav& tv, float tmin, const RtHit&
     } else if (hl) tv.cur = cl;
     else if (hr) tv.cur = cr;
     else tv.cur = rt_pop(tv, stk);
+}
+
+// The same step on a 4-wide quantised node (wide_bvh.cpp): the four child boxes are tested straight from their bytes --
+// t = byte * (step / d) + (origin - o) / d per plane -- the hit children are ordered by entry distance, the nearest is
+// entered and the others are pushed farthest first.  The order comes from sorting four 32-bit keys, the entry distance's
+// bit pattern (positive floats order like integers), with the child codes carried along.
+RT_HD float rt_ubyte(uint32_t w, int k) { return (float)((w >> (8 * k)) & 255u); }
+template <bool STATS, class Nodes, class Stack>
+RT_HD void rt_node_step4(const Nodes& nodes, RtTrav& tv, float tmin, const RtHit& hit, Stack& stk, RtCounters* wc) {
+    rt_f4 q[4];
+    const int32_t node = tv.cur;
+    nodes.get(node, q);
+    if (STATS) wc->wnodes++;
+    const float ax = q[0].w * tv.inv.x, ay = q[3].z * tv.inv.y, az = q[3].w * tv.inv.z;
+    const float bx = (q[0].x - tv.o.x) * tv.inv.x, by = (q[0].y - tv.o.y) * tv.inv.y, bz = (q[0].z - tv.o.z) * tv.inv.z;
+    // Per axis the ray enters through the child's lo plane when it travels in + direction, else through its hi plane: the
+    // near and far byte words are chosen once per node, and a child costs six conversions and six multiply-adds.  (A zero
+    // direction component makes 0 * inf = NaN planes, which max3 / min3 drop: that axis then does not constrain the box.)
+    const bool px = tv.d.x >= 0.0f, py = tv.d.y >= 0.0f, pz = tv.d.z >= 0.0f;
+    const uint32_t lox = (uint32_t)f2i(q[1].x), loy = (uint32_t)f2i(q[1].y), loz = (uint32_t)f2i(q[1].z), hix = (uint32_t)f2i(q[1].w),
+                   hiy = (uint32_t)f2i(q[2].x), hiz = (uint32_t)f2i(q[2].y);
+    const uint32_t nx = px ? lox : hix, fx = px ? hix : lox, ny = py ? loy : hiy, fy = py ? hiy : loy, nz = pz ? loz : hiz, fz = pz ? hiz : loz;
+    int32_t c0 = f2i(q[2].z), c1 = f2i(q[2].w), c2 = f2i(q[3].x), c3 = f2i(q[3].y);
+    uint32_t k0, k1, k2, k3;
+#define RT_WIDE_CHILD(K, CODE, KEY)                                                                                       \
+    {                                                                                                                     \
+        float tn = fmaxf(fmaxf(fmaf(rt_ubyte(nx, K), ax, bx), fmaf(rt_ubyte(ny, K), ay, by)), fmaxf(fmaf(rt_ubyte(nz, K), az, bz), tmin));   \
+        float tf = fminf(fminf(fmaf(rt_ubyte(fx, K), ax, bx), fmaf(rt_ubyte(fy, K), ay, by)), fminf(fmaf(rt_ubyte(fz, K), az, bz), hit.t));  \
+        KEY = (CODE != RT_EMPTY_STACK && tn <= tf) ? (uint32_t)f2i(tn) : 0xFFFFFFFFu;                                      \
+    }
+    RT_WIDE_CHILD(0, c0, k0) RT_WIDE_CHILD(1, c1, k1) RT_WIDE_CHILD(2, c2, k2) RT_WIDE_CHILD(3, c3, k3)
+#undef RT_WIDE_CHILD
+#define RT_CSWAP(KA, CA, KB, CB) { bool sw = KB < KA; uint32_t kl = sw ? KB : KA, kh = sw ? KA : KB; int32_t cl = sw ? CB : CA, ch = sw ? CA : CB; KA = kl; KB = kh; CA = cl; CB = ch; }
+    RT_CSWAP(k0, c0, k1, c1) RT_CSWAP(k2, c2, k3, c3) RT_CSWAP(k0, c0, k2, c2) RT_CSWAP(k1, c1, k3, c3) RT_CSWAP(k1, c1, k2, c2)
+#undef RT_CSWAP
+    // misses sort last: the hit children are k0 .. k(n-1).  The stack holds the tree's worst case (wide_bvh.cpp computes it),
+    // the capacity test only guards memory.
+    if (k3 != 0xFFFFFFFFu && tv.sp < stk.cap()) stk.put(tv.sp++, node, 0, c3);
+    if (k2 != 0xFFFFFFFFu && tv.sp < stk.cap()) stk.put(tv.sp++, node, 0, c2);
+    if (k1 != 0xFFFFFFFFu && tv.sp < stk.cap()) stk.put(tv.sp++, node, 0, c1);
+    tv.cur = k0 != 0xFFFFFFFFu ? c0 : rt_pop(tv, stk);
+}
+template <bool STATS, class Nodes, class Stack>
+RT_HD void rt_inner_step(const Nodes& nodes, RtTrav& tv, float tmin, const RtHit& hit, Stack& stk, RtCounters* wc) {
+    if constexpr (Nodes::kWide) rt_node_step4<STATS>(nodes, tv, tmin, hit, stk, wc);
+    else rt_node_step<STATS>(nodes, tv, tmin, hit, stk, wc);
 }
 
 // tv.cur is the sentinel pushed when an instance was entered: back to the world-space ray.
@@ -407,8 +473,8 @@ RT_HD void rt_leaf_test(const Prims& prims, int32_t leaf, float time, float tmin
 }
 
 // tv.cur is an instance leaf: push the sentinel, take the ray to the instance's object space, go to its root.
-template <bool STATS, class Prims, class Stack>
-RT_HD void rt_instance_enter(const Prims& prims, v3 wo, v3 wd, RtTrav& tv, Stack& stk, RtCounters* wc) {
+template <bool STATS, class Nodes, class Prims, class Stack>
+RT_HD void rt_instance_enter(const Nodes& nodes, const Prims& prims, v3 wo, v3 wd, RtTrav& tv, Stack& stk, RtCounters* wc) {
     int32_t ii = (int32_t)(~(uint32_t)tv.cur & 0x3FFFFFFFu);
     rt_f4 i0, i1;
     prims.instance((uint32_t)ii, i0, i1);
@@ -416,14 +482,14 @@ RT_HD void rt_instance_enter(const Prims& prims, v3 wo, v3 wd, RtTrav& tv, Stack
     tv.inst = ii;
     if (STATS) wc->instances++;
     rt_trav_ray(tv, rt_to_object_point(i0, i1, wo), rt_to_object_dir(i0, wd));
-    tv.cur = f2i(i1.y);
+    tv.cur = nodes.instance_root(ii, f2i(i1.y));
 }
 
 // tv.cur is a leaf code (< 0): enter the instance, or intersect the leaf's primitives; then pop.
-template <bool STATS, class Prims, class Stack>
-RT_HD void rt_leaf_step(const Prims& prims, v3 wo, v3 wd, float time, float tmin, uint32_t src, RtTrav& tv, RtHit& hit,
+template <bool STATS, class Nodes, class Prims, class Stack>
+RT_HD void rt_leaf_step(const Nodes& nodes, const Prims& prims, v3 wo, v3 wd, float time, float tmin, uint32_t src, RtTrav& tv, RtHit& hit,
                         Stack& stk, RtCounters* wc) {
-    if (~(uint32_t)tv.cur & RT_LEAF_INSTANCE_BIT) { rt_instance_enter<STATS>(prims, wo, wd, tv, stk, wc); return; }
+    if (~(uint32_t)tv.cur & RT_LEAF_INSTANCE_BIT) { rt_instance_enter<STATS>(nodes, prims, wo, wd, tv, stk, wc); return; }
     rt_leaf_test<STATS>(prims, tv.cur, time, tmin, src, tv, hit, wc);
     tv.cur = rt_pop(tv, stk);
 }
@@ -435,20 +501,29 @@ template <bool STATS, class Nodes, class Prims, class Stack>
 RT_HD void rt_closest_hit_in(const RtSceneView& sc, const Nodes& nodes, const Prims& prims, v3 wo, v3 wd, float time, float tmin, uint32_t src,
                              Stack& stk, RtHit& hit, RtCounters* wc) {
     RtTrav tv;
-    rt_trav_begin(sc, wo, wd, tv);
+    rt_trav_begin(sc, nodes, wo, wd, tv);
     while (tv.cur != RT_EMPTY_STACK) {
-        while (rt_is_inner(tv.cur)) rt_node_step<STATS>(nodes, tv, tmin, hit, stk, wc);
+        while (rt_is_inner(tv.cur)) rt_inner_step<STATS>(nodes, tv, tmin, hit, stk, wc);
         if (tv.cur >= 0) {
             if (tv.cur != RT_EMPTY_STACK) rt_sentinel_step(wo, wd, tv, stk);
             continue;
         }
-        do rt_leaf_step<STATS>(prims, wo, wd, time, tmin, src, tv, hit, stk, wc); while (tv.cur < 0);
+        do rt_leaf_step<STATS>(nodes, prims, wo, wd, time, tmin, src, tv, hit, stk, wc); while (tv.cur < 0);
     }
 }
 template <bool STATS, class Stack>
 RT_HD void rt_closest_hit(const RtSceneView& sc, v3 wo, v3 wd, float time, float tmin, uint32_t src, Stack& stk, RtHit& hit,
                           RtCounters* wc) {
     RtGlobalNodes nodes; nodes.nodes = sc.nodes;
+    RtGlobalPrims prims; prims.sc = &sc;
+    rt_closest_hit_in<STATS>(sc, nodes, prims, wo, wd, time, tmin, src, stk, hit, wc);
+}
+
+// The same search through the 4-wide tree.
+template <bool STATS, class Stack>
+RT_HD void rt_closest_hit_wide(const RtSceneView& sc, v3 wo, v3 wd, float time, float tmin, uint32_t src, Stack& stk, RtHit& hit,
+                               RtCounters* wc) {
+    RtGlobalWideNodes nodes; nodes.nodes = sc.wnodes; nodes.inst_roots = sc.winst_roots;
     RtGlobalPrims prims; prims.sc = &sc;
     rt_closest_hit_in<STATS>(sc, nodes, prims, wo, wd, time, tmin, src, stk, hit, wc);
 }

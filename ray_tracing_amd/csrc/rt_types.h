@@ -98,6 +98,10 @@ struct RtSceneView {
     int32_t n_nodes, n_spheres, n_mspheres, n_rects, n_instances, n_ops, n_media, n_materials, n_textures, n_perlin;
     int32_t max_stack;      // deepest traversal stack the BVH can need (TLAS depth + sentinel + BLAS depth)
     int32_t n_boxes;
+    // The same tree collapsed to 4-wide nodes with quantised child boxes (layout: wide_bvh.cpp), 4 x rt_f4 per node.
+    const rt_f4* wnodes;
+    const int32_t* winst_roots;   // per instance: the wide node that roots its subtree
+    int32_t n_wnodes, wroot, wmax_stack;
 };
 
 // Camera in device form (cameras.rs:23-34); dir0 = lower_left_corner - origin is precomputed in

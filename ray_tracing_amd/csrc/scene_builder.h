@@ -138,6 +138,9 @@ struct FlatScene {
     std::vector<rt_i2> sphere_meta, msphere_meta, rect_meta;
     std::vector<uint8_t> perlin_perm;
     std::vector<rt_f4> tlas_items;   // deferred top level (flatten(..., defer_top)): 2 records per item, see lbvh.h
+    std::vector<rt_f4> wnodes;       // the 4-wide quantised form of `nodes` (build_wide_bvh)
+    std::vector<int32_t> winst_roots;
+    int wroot = -1, wmax_stack = 0;
     int root = -1, max_stack = 0, tlas_depth = 0, blas_depth = 0, n_ids = 0;
     double world_box[6] = {0, 0, 0, 0, 0, 0};
     RtSceneView view() const;  // host pointers
@@ -147,6 +150,8 @@ struct FlatScene {
 // defer_top: the top-level BVH is not built; out.tlas_items holds its leaves (unless there are fewer than two, in which
 // case the normal builder runs) and out.root stays -1 until lbvh_finish_host or the device builder appends the nodes.
 bool flatten(const Builder& b, HittableObj world, FlatScene& out, std::string& err, bool defer_top = false);
+// Collapses the finished binary tree (nodes, root, instances) into the 4-wide quantised tree (wide_bvh.cpp).
+void build_wide_bvh(FlatScene& f);
 // Builds the deferred top level as a linear BVH on the host, with the per-element steps of lbvh.h in plain loops.
 bool lbvh_finish_host(FlatScene& f, std::string& err);
 // Scene box of the deferred items -> Morton frame.

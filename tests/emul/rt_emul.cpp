@@ -3,6 +3,7 @@
 // logic can be checked against the f64 oracle in a container without a GPU.  It is never loaded by
 // the ray_tracing_amd package, never shipped, and is not a fallback of any kind: it exists so that a
 // logic error is found on the CPU instead of costing a GPU run.
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -11,12 +12,19 @@
 #include "../../ray_tracing_amd/csrc/scene_builder.h"
 
 struct ArrStack {
-    int v[RT_STACK_DEPTH];
+    int v[128];   // the 4-wide tree pushes up to three children per node: deeper than RT_STACK_DEPTH
     void put(int i, int, int, int code) { v[i] = code; }
     void put_sentinel(int i) { v[i] = RT_SENTINEL; }
     int take(int i) const { return v[i]; }
-    int cap() const { return RT_STACK_DEPTH; }
+    int cap() const { return 128; }
 };
+// EMUL_WIDE_BVH=1 in the environment: every closest-hit search goes through the 4-wide quantised tree instead of the binary one.
+static bool use_wide() { const char* e = std::getenv("EMUL_WIDE_BVH"); return e && std::atoi(e) != 0; }
+template <class Stack>
+static void closest(const RtSceneView& sc, v3 o, v3 d, float time, uint32_t src, Stack& stk, RtHit& hit) {
+    if (use_wide()) rt_closest_hit_wide<false>(sc, o, d, time, RT_TMIN, src, stk, hit, nullptr);
+    else rt_closest_hit<false>(sc, o, d, time, RT_TMIN, src, stk, hit, nullptr);
+}
 
 static void make_cam(const RtCamera* cam, RtCameraDev& cd) {
     rt::CameraDesc d;
@@ -53,7 +61,7 @@ void emul_trace_primary(const RtSceneView* sc, const RtCamera* cam, const RtRend
         rt_camera_ray(cd, fr, pixel, (uint32_t)sample, o, d, time);
         ArrStack stk;
         RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
-        rt_closest_hit<false>(*sc, o, d, time, RT_TMIN, RT_HIT_NONE, stk, hit, nullptr);
+        closest(*sc, o, d, time, RT_HIT_NONE, stk, hit);
         if (sc->n_media > 0) {
             uint32_t rnd[4]; rt_philox(pixel, (uint32_t)sample, 1u, 0u, fr.key0, fr.key1, rnd);
             rt_media_hits(*sc, o, d, time, RT_TMIN, pixel, (uint32_t)sample, 1u, fr.key0, fr.key1, rnd, hit);
@@ -86,7 +94,7 @@ void emul_render(const RtSceneView* sc, const RtCamera* cam, const RtRenderParam
                     rays[(size_t)tid]++;
                     ArrStack stk;
                     RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
-                    rt_closest_hit<false>(*sc, o, d, time, RT_TMIN, src, stk, hit, nullptr);
+                    closest(*sc, o, d, time, src, stk, hit);
                     uint32_t rnd[4]; rt_philox(pixel, sample, (uint32_t)bounce, 0u, fr.key0, fr.key1, rnd);
                     if (sc->n_media > 0) rt_media_hits(*sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, fr.key0, fr.key1, rnd, hit);
                     if (hit.code == RT_HIT_NONE) { L = L + beta * mk3(fr.background[0], fr.background[1], fr.background[2]); break; }
@@ -119,7 +127,7 @@ void emul_scatter_rays(const RtSceneView* sc, const float* rays, int32_t n, uint
         uint32_t pixel = pixel0 + (uint32_t)i, key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32);
         ArrStack stk;
         RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
-        rt_closest_hit<false>(*sc, o, d, time, RT_TMIN, RT_HIT_NONE, stk, hit, nullptr);
+        closest(*sc, o, d, time, RT_HIT_NONE, stk, hit);
         uint32_t rnd[4]; rt_philox(pixel, sample, (uint32_t)bounce, 0u, key0, key1, rnd);
         if (sc->n_media > 0) rt_media_hits(*sc, o, d, time, RT_TMIN, pixel, sample, (uint32_t)bounce, key0, key1, rnd, hit);
         float* w = out + 14 * (size_t)i;

@@ -195,3 +195,95 @@ def test_linear_bvh_traversal_matches_oracle():
         agree, rel = primary_agreement(lin, o)
         assert agree >= 0.999 and rel <= 1e-4, (name, agree, rel)
         assert np.array_equal(lin["id"], sah["id"]) and np.array_equal(lin["t"], sah["t"])
+
+
+# ---------------------------------------------------------------------------------------------- the 4-wide quantised tree
+def wide_arrays(flat):
+    base = flat.view + 15 * 8 + 13 * 4 + 4            # after the binary view's pointers and ints (padded to 8 bytes)
+    ptrs = (C.c_void_p * 2).from_address(base)
+    n_wnodes, wroot, wmax_stack = list((C.c_int32 * 3).from_address(base + 16))
+    nodes = np.ctypeslib.as_array((C.c_uint32 * (16 * n_wnodes)).from_address(ptrs[0])).reshape(-1, 16).copy() if n_wnodes else np.zeros((0, 16), np.uint32)
+    return nodes, ptrs[1], wroot, wmax_stack
+
+
+def wide_children(node):
+    """[(lo, hi, code)] of the present children of one wide node, boxes decoded as the kernel does (origin + byte * step)."""
+    org = node[0:3].view(np.float32).astype(np.float64)
+    step = np.array([node[3:4].view(np.float32)[0], node[14:15].view(np.float32)[0], node[15:16].view(np.float32)[0]], dtype=np.float64)
+    q = node[4:10]
+    codes = node[10:14].view(np.int32)
+    out = []
+    for k in range(4):
+        if codes[k] == 0x7FFFFFFF:
+            continue
+        lo = org + step * np.array([(int(q[a]) >> (8 * k)) & 255 for a in range(3)])
+        hi = org + step * np.array([(int(q[3 + a]) >> (8 * k)) & 255 for a in range(3)])
+        out.append((lo, hi, int(codes[k])))
+    return out
+
+
+@pytest.mark.parametrize("name", ["orig_img.yml", "random.yml", "cornell_box.yml", "final_scene.yml", "showcase.yml"])
+def test_wide_bvh_invariants(name):
+    """Every primitive is reachable exactly once through the wide tree, every decoded child box contains what is below it
+    (quantisation only grows boxes), and the recorded stack bound covers the deepest path."""
+    cfg, cam, b, world, _ = scene_pair(name)
+    flat = FlatScene(b, world)
+    a = arrays(flat)
+    wn, inst_roots_ptr, wroot, wmax = wide_arrays(flat)
+    n_inst = a["instances"].shape[0]
+    inst_roots = list((C.c_int32 * n_inst).from_address(inst_roots_ptr)) if n_inst else []
+    seen = set()
+
+    def walk_wide(n, need, in_blas):
+        kids = wide_children(wn[n])
+        assert 1 <= len(kids) <= 4
+        here = need + len(kids) - 1
+        deepest = here
+        out_lo, out_hi = np.full(3, np.inf), np.full(3, -np.inf)
+        for lo, hi, c in kids:
+            if c >= 0:
+                clo, chi, d = walk_wide(c, here, in_blas)
+                deepest = max(deepest, d)
+            else:
+                x = ~c & 0x7FFFFFFF
+                if x & LEAF_INST:
+                    assert not in_blas
+                    _, _, d = walk_wide(inst_roots[x & 0x3FFFFFFF], here + 1, True)     # + the sentinel
+                    deepest = max(deepest, d)
+                    clo, chi = lo, hi
+                else:
+                    kind, cnt, first = (x >> 28) & 3, ((x >> 26) & 3) + 1, x & 0x03FFFFFF
+                    clo, chi = np.full(3, np.inf), np.full(3, -np.inf)
+                    for i in range(first, first + cnt):
+                        assert (kind, i) not in seen
+                        seen.add((kind, i))
+                        plo, phi = prim_box(a, kind, i)
+                        clo, chi = np.minimum(clo, plo), np.maximum(chi, phi)
+            assert np.all(lo <= clo + 1e-3 * (1 + np.abs(clo))) and np.all(hi >= chi - 1e-3 * (1 + np.abs(chi))), (n, lo, clo, hi, chi)
+            out_lo, out_hi = np.minimum(out_lo, clo), np.maximum(out_hi, chi)       # what is really below: each level quantises on its own grid
+        return out_lo, out_hi, deepest
+
+    _, _, deepest = walk_wide(wroot, 0, False)
+    assert deepest <= wmax
+    seen2 = set()
+    walk(a, a["root"], seen2, 0, dict(depth=0, inst=[]), False)
+    assert seen == seen2                                # the wide tree reaches exactly the primitives of the binary tree
+
+
+@pytest.mark.parametrize("flags", [0, rt.RT_BVH_LINEAR])
+def test_wide_bvh_traversal_matches_oracle(flags, monkeypatch):
+    """The fp32 traversal of the wide tree (host build of the kernels' functions) against the oracle on a sphere field."""
+    from helpers import OracleBuilder, OracleCamera, RENDER_SEED, SCENE_SEED, emul_trace_primary, oracle_trace_primary, primary_agreement
+    b, ob = rt.Builder(), OracleBuilder()
+    w = b.canned_scene("Synthetic:30000", SCENE_SEED)
+    ob.set_world(ob.canned_scene("Synthetic:30000", SCENE_SEED))
+    flat = FlatScene(b, w, flags)
+    cam = rt.make_camera((0, 260, 1500), (0, 60, 0), (0, 1, 0), 40.0, 16 / 9, 0.1, 10.0)
+    p = rt.render_params(240, 135, 1, 50, RENDER_SEED)
+    o = oracle_trace_primary(ob, OracleCamera(cam), 240, 135, 0, RENDER_SEED)
+    plain = emul_trace_primary(flat, cam, p, 0)
+    monkeypatch.setenv("EMUL_WIDE_BVH", "1")
+    wide = emul_trace_primary(flat, cam, p, 0)
+    agree, rel = primary_agreement(wide, o)
+    assert agree >= 0.9999 and rel <= 1e-4, (agree, rel)
+    assert np.array_equal(wide["id"], plain["id"]) and np.array_equal(wide["t"], plain["t"])     # closest hits do not depend on the tree

@@ -112,11 +112,13 @@ def test_synthetic_sphere_field_matches_oracle(gpu_required):
     scene.close()
 
 
-@pytest.mark.parametrize("env", [{"RT_TRACE_WIDE_STACK": "1"}, {"RT_TRACE_BLOCK": "256"}, {"RT_SHADE_LDS": "0"}, {"RT_SHADE_FUSED": "0"}])
+@pytest.mark.parametrize("env", [{"RT_TRACE_WIDE_STACK": "1"}, {"RT_TRACE_BLOCK": "256"}, {"RT_SHADE_LDS": "0"}, {"RT_SHADE_FUSED": "0"},
+                                 {"RT_TRACE_BVH4": "1", "RT_SHADE_FUSED": "0"}])
 @pytest.mark.parametrize("name", ["cornell.yml", "final_scene.yml", "showcase.yml", "rectangle.yml", "orig_img.yml", "cornell_box.yml", "two_spheres.yml"])
 def test_kernel_variants_agree(gpu_required, name, env):
-    """k_trace picks its block shape, stack form and what lives in LDS per scene, and shading runs either from tables in LDS
-    with staged ray records (k_shade_lds) or from global memory (k_shade); every choice must give the very same image."""
+    """k_trace picks its block shape, stack form, node format (binary or 4-wide quantised) and what lives in LDS per scene, and
+    shading runs either from tables in LDS with staged ray records (k_shade_lds) or from global memory (k_shade); every choice
+    must give the very same image."""
     cfg, cam = config_camera(name)
     p = rt.render_params(200, 200, 4, cfg.max_depth, RENDER_SEED)
 

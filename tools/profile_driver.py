@@ -31,4 +31,6 @@ for i in range(reps):
     p = rt.render_params(cfg.image_width, cfg.image_height, spp, cfg.max_depth, 0x5EED0002, sample_offset=i * spp, paths_per_pass=ppp, flags=abl, background=background)
     st = scene.render_device(cam, p, acc.data_ptr(), None, None)
     print("flags %d %s spp %d: %.2f ms, %.1f Mrays/s, bounce loop %.2f ms (trace %.2f ms), passes %d" % (abl, name, spp, st.seconds * 1e3, st.rays / st.seconds / 1e6, st.kernel_ms_extend, st.kernel_ms_trace, st.passes), flush=True)
+if abl & 2:
+    print("work per ray:", " ".join("%s=%.2f" % (n, st.work[i] / st.rays) for i, n in ((0, "nodes"), (15, "wide_nodes"), (1, "spheres"), (7, "boxes"), (3, "rects"), (4, "instances"))), flush=True)
 print("library:", [l.split()[-1] for l in open("/proc/self/maps") if "ray_tracing_amd" in l and l.rstrip().endswith(".so")][:1], flush=True)
