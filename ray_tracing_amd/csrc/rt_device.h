@@ -406,18 +406,22 @@ RT_HD void rt_node_step4(const Nodes& nodes, RtTrav& tv, float tmin, const RtHit
     {                                                                                                                     \
         float tn = fmaxf(fmaxf(fmaf(rt_ubyte(nx, K), ax, bx), fmaf(rt_ubyte(ny, K), ay, by)), fmaxf(fmaf(rt_ubyte(nz, K), az, bz), tmin));   \
         float tf = fminf(fminf(fmaf(rt_ubyte(fx, K), ax, bx), fmaf(rt_ubyte(fy, K), ay, by)), fminf(fmaf(rt_ubyte(fz, K), az, bz), hit.t));  \
-        KEY = (CODE != RT_EMPTY_STACK && tn <= tf) ? (uint32_t)f2i(tn) : 0xFFFFFFFFu;                                      \
+        KEY = tn <= tf ? (uint32_t)f2i(tn) : 0xFFFFFFFFu;   /* an absent child's inverted box (lo 255, hi 0) never passes */ \
     }
     RT_WIDE_CHILD(0, c0, k0) RT_WIDE_CHILD(1, c1, k1) RT_WIDE_CHILD(2, c2, k2) RT_WIDE_CHILD(3, c3, k3)
 #undef RT_WIDE_CHILD
 #define RT_CSWAP(KA, CA, KB, CB) { bool sw = KB < KA; uint32_t kl = sw ? KB : KA, kh = sw ? KA : KB; int32_t cl = sw ? CB : CA, ch = sw ? CA : CB; KA = kl; KB = kh; CA = cl; CB = ch; }
+#ifdef RT_WIDE_NEAREST_ONLY   /* experiment: only the nearest child is singled out, the others are pushed in slot order */
+    RT_CSWAP(k0, c0, k1, c1) RT_CSWAP(k2, c2, k3, c3) RT_CSWAP(k0, c0, k2, c2)
+#else
     RT_CSWAP(k0, c0, k1, c1) RT_CSWAP(k2, c2, k3, c3) RT_CSWAP(k0, c0, k2, c2) RT_CSWAP(k1, c1, k3, c3) RT_CSWAP(k1, c1, k2, c2)
+#endif
 #undef RT_CSWAP
-    // misses sort last: the hit children are k0 .. k(n-1).  The stack holds the tree's worst case (wide_bvh.cpp computes it),
-    // the capacity test only guards memory.
-    if (k3 != 0xFFFFFFFFu && tv.sp < stk.cap()) stk.put(tv.sp++, node, 0, c3);
-    if (k2 != 0xFFFFFFFFu && tv.sp < stk.cap()) stk.put(tv.sp++, node, 0, c2);
-    if (k1 != 0xFFFFFFFFu && tv.sp < stk.cap()) stk.put(tv.sp++, node, 0, c1);
+    // Misses sort last: the hit children are k0 .. k(n-1).  The stack holds the tree's worst case by construction
+    // (wide_bvh.cpp computes it and the launch plan sizes the stack from it).
+    if (k3 != 0xFFFFFFFFu) stk.put(tv.sp++, node, 0, c3);
+    if (k2 != 0xFFFFFFFFu) stk.put(tv.sp++, node, 0, c2);
+    if (k1 != 0xFFFFFFFFu) stk.put(tv.sp++, node, 0, c1);
     tv.cur = k0 != 0xFFFFFFFFu ? c0 : rt_pop(tv, stk);
 }
 template <bool STATS, class Nodes, class Stack>
