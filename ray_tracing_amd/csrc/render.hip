@@ -303,7 +303,13 @@ struct ShadeMedia {   // medium records: the first RT_SHADE_MEDIA_LDS media from
 // contribution slot; out.alive = the path continues with the ray out.na / nb / nc.  out.postponed = the hit needs a costly
 // texture and `may_postpone` was set: nothing has been written for the ray then.
 // Tab: see RtGlobalTables; MediaSrc: see rt_media_hits.  STATS = true also counts shades per material kind into `work`.
-struct ShadeOut { bool alive, postponed; rt_f4 na, nb, nc; };
+struct ShadeOut { bool alive, postponed; int cls; rt_f4 na, nb, nc; };
+// Classes of hits that a wave may set aside and shade together later (k_shade_lds): 0 = the material's texture tree holds a
+// Noise (Perlin turbulence, ~1300 instructions).  RT_POSTPONE_CLASSES = 2 adds dielectrics, 3 also metals (measured: not worth
+// it -- a postponed hit repeats the medium tests and the hit record, which cost more than the divergence they avoid).
+#ifndef RT_POSTPONE_CLASSES
+#define RT_POSTPONE_CLASSES 1
+#endif
 template <bool STATS, class Tab, class MediaSrc>
 __device__ __forceinline__ void shade_ray(const RtSceneView& sc, const Tab& tab, const MediaSrc& msrc, const RtFrameDev& fr, int bounce,
                                           rt_f4 a, rt_f4 b, rt_f4 c, rt_f4 h, bool may_postpone, rt_f4* contrib,
@@ -329,7 +335,12 @@ __device__ __forceinline__ void shade_ray(const RtSceneView& sc, const Tab& tab,
         rt_surface(tab, o, d, time, hit, false, sf);
         rt_f4 a0, a1;
         tab.material(sf.mat, a0, a1);
-        out.postponed = may_postpone && f2i(a1.w) != 0;
+        if (may_postpone) {
+            const int mtype_ = f2i(a0.x);
+            if (f2i(a1.w) != 0) { out.postponed = true; out.cls = 0; }
+            else if (RT_POSTPONE_CLASSES > 1 && mtype_ == RT_MAT_DIELECTRIC) { out.postponed = true; out.cls = 1; }
+            else if (RT_POSTPONE_CLASSES > 2 && mtype_ == RT_MAT_METAL) { out.postponed = true; out.cls = 2; }
+        }
         if (!out.postponed) {
             v3 atten, dir, emitted;
             bool scattered = rt_scatter(tab, sf, d, rt_u24(rnd[0]), rt_u24(rnd[1]), atten, dir, emitted);
@@ -364,7 +375,7 @@ __device__ __forceinline__ void shade_ray(const RtSceneView& sc, const Tab& tab,
     }
 }
 __device__ __forceinline__ void shade_out_clear(ShadeOut& out) {
-    out.alive = false; out.postponed = false;
+    out.alive = false; out.postponed = false; out.cls = 0;
     out.na.x = out.na.y = out.na.z = out.na.w = out.nb.x = out.nb.y = out.nb.z = out.nb.w = out.nc.x = out.nc.y = out.nc.z = out.nc.w = 0.0f;
 }
 // Append of the scattered rays of one wave to the output queue: one atomic per wave, slot = base + rank among the live
@@ -548,10 +559,9 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     lds_f4* stage = tab.lds + pl.off_stage + wave * 256u;
-    lds_u32* later = (lds_u32*)(tab.lds + pl.off_later) + wave * 128u;
-    const bool may_postpone = sc.n_perlin > 0;
+    lds_u32* later = (lds_u32*)(tab.lds + pl.off_later) + wave * (128u * RT_POSTPONE_CLASSES);
+    const bool may_postpone = sc.n_perlin > 0 || RT_POSTPONE_CLASSES > 1;
     const uint32_t stride = gridDim.x * 1024u;
-    uint32_t n_later = 0;                                              // wave-uniform
     uint32_t base = blockIdx.x * 1024u + wave * 64u;                   // wave-uniform
     TraceStack<true> stk;   // FUSED
     stk.base = (lds_int*)(tab.lds + pl.off_stack) + threadIdx.x; stk.depth = pl.stack_cap; stk.stride = 1024;
@@ -564,45 +574,57 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
     };
     if (base < n) shade_stage<FUSED>(ia, ib, ic, hits, min(base + lane, n - 1u), stage);
     bool landed = false;                                               // the staged records are known to have arrived
-    for (; base < n; base += stride) {
-        const uint32_t i = base + lane;
-        if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        rt_f4 a = lds_ld4(stage + lane), b = lds_ld4(stage + 64 + lane), c = lds_ld4(stage + 128 + lane), h;
-        if (!FUSED) h = lds_ld4(stage + 192 + lane);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the records are in registers, the staging area is free
-        if (base + stride < n) shade_stage<FUSED>(ia, ib, ic, hits, min(i + stride, n - 1u), stage);
-        ShadeOut out; shade_out_clear(out);
-        if (i < n) {
-            if (FUSED) h = closest(a, b);
-            shade_ray<false>(sc, tab, tab, fr, bounce, a, b, c, h, may_postpone, contrib, nullptr, out);
+    // One loop body, one inlined copy of the shading code: an iteration shades either 64 postponed hits of one class (as soon
+    // as a class has that many, and whatever is left once the queue is exhausted) or the wave's next 64 staged queue entries.
+    uint32_t n_later[RT_POSTPONE_CLASSES];                             // wave-uniform
+#pragma unroll
+    for (int k = 0; k < RT_POSTPONE_CLASSES; ++k) n_later[k] = 0;
+    for (;;) {
+        int flush = -1;
+#pragma unroll
+        for (int k = 0; k < RT_POSTPONE_CLASSES; ++k) if (n_later[k] >= 64u || (base >= n && n_later[k] > 0u)) flush = k;
+        if (flush < 0 && base >= n) break;
+        rt_f4 a, b, c, h;
+        bool valid, may_post;
+        uint32_t i;
+        if (flush >= 0) {                                              // at most 127 entries in a list: 64 are added to < 64
+            uint32_t have = 0;
+#pragma unroll
+            for (int k = 0; k < RT_POSTPONE_CLASSES; ++k) if (k == flush) { have = n_later[k]; n_later[k] = have >= 64u ? have - 64u : 0u; }
+            const uint32_t first = have >= 64u ? have - 64u : 0u, cnt = have - first;
+            __builtin_amdgcn_wave_barrier();
+            valid = lane < cnt; may_post = false;
+            i = valid ? later[(uint32_t)flush * 128u + first + lane] : 0u;
+            if (valid) { a = ld4(ia + i); b = ld4(ib + i); c = ld4(ic + i); if (!FUSED) h = ld4(hits + i); }
+            landed = true;                                             // these loads were issued after the staging and are waited for below
+        } else {
+            i = base + lane;
+            if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            a = lds_ld4(stage + lane); b = lds_ld4(stage + 64 + lane); c = lds_ld4(stage + 128 + lane);
+            if (!FUSED) h = lds_ld4(stage + 192 + lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the records are in registers, the staging area is free
+            if (base + stride < n) shade_stage<FUSED>(ia, ib, ic, hits, min(i + stride, n - 1u), stage);
+            valid = i < n; may_post = may_postpone;
+            base += stride;
+            landed = false;
         }
-        landed = shade_append(out, n_out_ptr, overflow, cap, oa, ob, oc);
-        unsigned long long pm = __ballot(out.postponed);
-        if (pm) {
-            uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-            if (out.postponed) later[n_later + rank] = i;
-            n_later += (uint32_t)__popcll(pm);
-            if (n_later >= 64u) {                                      // n_later < 128 always: at most 64 are added to < 64
-                n_later -= 64u;
-                __builtin_amdgcn_wave_barrier();
-                uint32_t j = later[n_later + lane];
-                ShadeOut o2; shade_out_clear(o2);
-                { rt_f4 a2 = ld4(ia + j), b2 = ld4(ib + j);
-                  shade_ray<false>(sc, tab, tab, fr, bounce, a2, b2, ld4(ic + j), FUSED ? closest(a2, b2) : ld4(hits + j), false, contrib, nullptr, o2); }
-                shade_append(o2, n_out_ptr, overflow, cap, oa, ob, oc);
-                landed = true;                                         // those loads were issued after the staging and have returned
+        ShadeOut out; shade_out_clear(out);
+        if (valid) {
+            if (FUSED) h = closest(a, b);
+            shade_ray<false>(sc, tab, tab, fr, bounce, a, b, c, h, may_post, contrib, nullptr, out);
+        }
+        if (shade_append(out, n_out_ptr, overflow, cap, oa, ob, oc)) landed = true;
+        if (may_post) {
+#pragma unroll
+            for (int k = 0; k < RT_POSTPONE_CLASSES; ++k) {
+                unsigned long long pm = __ballot(out.postponed && out.cls == k);
+                if (pm) {
+                    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                    if (out.postponed && out.cls == k) later[(uint32_t)k * 128u + n_later[k] + rank] = i;
+                    n_later[k] += (uint32_t)__popcll(pm);
+                }
             }
         }
-    }
-    if (n_later > 0) {
-        __builtin_amdgcn_wave_barrier();
-        uint32_t j = lane < n_later ? later[lane] : 0u;
-        ShadeOut o2; shade_out_clear(o2);
-        if (lane < n_later) {
-            rt_f4 a2 = ld4(ia + j), b2 = ld4(ib + j);
-            shade_ray<false>(sc, tab, tab, fr, bounce, a2, b2, ld4(ic + j), FUSED ? closest(a2, b2) : ld4(hits + j), false, contrib, nullptr, o2);
-        }
-        shade_append(o2, n_out_ptr, overflow, cap, oa, ob, oc);
     }
 }
 
@@ -850,7 +872,7 @@ static int plan_shade(RtScene* s) {
     long used = 0;   // 16-byte records
     auto place = [&](long n_records, int32_t& off) { off = (int32_t)used; used += n_records; };
     place(16 * 4 * 64, pl.off_stage);   // first: its addresses then fit 16 bits, whatever width the copy instruction takes from M0
-    place(16 * 128 / 4, pl.off_later);
+    place(16 * 128 * RT_POSTPONE_CLASSES / 4, pl.off_later);
     place(v.n_spheres, pl.off_spheres);                     place((v.n_spheres + 1) / 2, pl.off_sphere_meta);
     place((long)v.n_mspheres * RT_MSPHERE_F4, pl.off_mspheres); place((v.n_mspheres + 1) / 2, pl.off_msphere_meta);
     place((long)v.n_rects * RT_RECT_F4, pl.off_rects);      place((v.n_rects + 1) / 2, pl.off_rect_meta);

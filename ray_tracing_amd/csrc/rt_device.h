@@ -576,7 +576,9 @@ RT_HD void rt_boundary_pair(const RtSceneView& sc, rt_f4 m2, rt_f4 m3, rt_f4 m4,
     const v3 inv = mk3(rt_rcp(d.x), rt_rcp(d.y), rt_rcp(d.z));
     int s0 = rt_uniform(f2i(m2.y)), sn = rt_uniform(f2i(m2.z)), q0 = rt_uniform(f2i(m2.w)), qn = rt_uniform(f2i(m3.x));
     int r0 = rt_uniform(f2i(m3.y)), rn = rt_uniform(f2i(m3.z));
-#define RT_INSERT(t_) do { float t__ = (t_); if (t__ < a) { b = a; a = t__; } else if (t__ < b) b = t__; } while (0)
+    // insertion into the two smallest so far, without branches (written with an if / else-if the compiler addressed a and b
+    // as a two-element array in scratch memory)
+#define RT_INSERT(t_) do { float t__ = (t_); float hi__ = fmaxf(a, t__); a = fminf(a, t__); b = fminf(b, hi__); } while (0)
     for (int i = 0; i < sn; ++i) {
         rt_f4 s = ld4(sc.spheres + s0 + i);
         float tn, tf;
