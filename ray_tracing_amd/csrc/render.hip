@@ -290,6 +290,8 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, 
 }
 
 #define RT_SHADE_MEDIA_LDS 8
+#define RT_FLAT_LEAVES 8      /* most leaves a tree may have for the linear scan of the fused kernel */
+#define RT_FLAT_PRIMS 10      /* ... and most primitives */
 struct ShadeMedia {   // medium records: the first RT_SHADE_MEDIA_LDS media from the block's LDS copy
     const rt_f4* global; lds_f4* lds;
     __device__ __forceinline__ rt_f4 get(int m, int k) const {
@@ -465,6 +467,9 @@ struct RtShadePlan {
     int32_t off_spheres, off_sphere_meta, off_mspheres, off_msphere_meta, off_rects, off_rect_meta, off_boxes, off_instances, off_ops,
             off_materials, off_textures, off_media, off_perlin_vec, off_perlin_perm, off_stage, off_later;
     int32_t off_nodes, off_stack, stack_cap;   // FUSED only: the whole node array and a traversal stack of 32-bit entries per lane
+    // FUSED scenes of a handful of primitives: the leaves of the tree, listed; every ray then tests all of them in turn (the
+    // linear scan of src/objects.rs:67-78) instead of walking the tree -- each lane runs the same tests, so no lane ever waits.
+    int32_t n_flat; int32_t flat_leaf[RT_FLAT_LEAVES];
 };
 typedef int __attribute__((ext_vector_type(2))) rt_vi2;
 typedef __attribute__((address_space(3))) const rt_vi2 lds_i2;
@@ -568,7 +573,11 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
     // the closest hit of ray (a, b) as the record k_trace would have written
     auto closest = [&](rt_f4 a, rt_f4 b) -> rt_f4 {
         RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
-        rt_closest_hit_in<false>(sc, tab, tab, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, RT_TMIN, (uint32_t)f2i(b.w), stk, hit, nullptr);
+        if (pl.n_flat > 0) {
+            RtTrav tv; rt_trav_ray(tv, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z)); tv.inst = -1; tv.sp = 0; tv.cur = RT_EMPTY_STACK;
+            for (int k = 0; k < pl.n_flat; ++k) rt_leaf_test<false>(tab, pl.flat_leaf[k], a.w, RT_TMIN, (uint32_t)f2i(b.w), tv, hit, nullptr);
+        } else
+            rt_closest_hit_in<false>(sc, tab, tab, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, RT_TMIN, (uint32_t)f2i(b.w), stk, hit, nullptr);
         rt_f4 h; h.x = hit.t; h.y = i2f((int)hit.code); h.z = i2f(hit.inst); h.w = 0.0f;
         return h;
     };
@@ -900,6 +909,30 @@ static int plan_shade(RtScene* s) {
         int32_t on = (int32_t)with; with += (long)v.n_nodes * 4;
         int32_t os = (int32_t)with; with += (long)std::max(1, s->flat.max_stack) * 1024 / 4;
         if (with * 16 <= kLdsBudget) { pl.off_nodes = on; pl.off_stack = os; pl.stack_cap = std::max(1, s->flat.max_stack); used = with; s->shade_fused = true; }
+    }
+    // the leaves of such a tree, for the linear scan (RT_SHADE_FLAT = 0 keeps the tree walk)
+    pl.n_flat = 0;
+    const char* efl = std::getenv("RT_SHADE_FLAT");
+    if (s->shade_fused && !(efl && std::atoi(efl) == 0)) {
+        std::vector<int32_t> leaves; int prims = 0; bool ok = true;
+        std::vector<int> todo(1, v.root);
+        const std::vector<rt_f4>& nd = s->flat.nodes;
+        while (!todo.empty() && ok) {
+            int n = todo.back(); todo.pop_back();
+            int32_t kids[2]; std::memcpy(&kids[0], &nd[(size_t)n * 4 + 3].x, 4); std::memcpy(&kids[1], &nd[(size_t)n * 4 + 3].y, 4);
+            const bool empty[2] = {!(nd[(size_t)n * 4].x <= nd[(size_t)n * 4].w), !(nd[(size_t)n * 4 + 1].z <= nd[(size_t)n * 4 + 2].y)};   // min.x > max.x: absent child
+            for (int c = 1; c >= 0; --c) {
+                if (empty[c] || (c == 1 && kids[1] == kids[0] && kids[0] < 0)) continue;
+                if (kids[c] >= 0) { todo.push_back(kids[c]); continue; }
+                uint32_t x = ~(uint32_t)kids[c];
+                if (x & RT_LEAF_INSTANCE_BIT) { ok = false; break; }
+                leaves.push_back(kids[c]); prims += (int)((x >> 26) & 3u) + 1;
+            }
+        }
+        if (ok && !leaves.empty() && (int)leaves.size() <= RT_FLAT_LEAVES && prims <= RT_FLAT_PRIMS) {
+            pl.n_flat = (int32_t)leaves.size();
+            for (size_t k = 0; k < leaves.size(); ++k) pl.flat_leaf[k] = leaves[k];
+        }
     }
     s->shade_lds_bytes = (int)(used * 16);
     return RT_OK;
