@@ -119,8 +119,21 @@ typedef struct RtSceneInfo {
     double world_box[6];
     uint64_t device_bytes;
     double bvh_build_seconds;   /* RT_BVH_LINEAR scenes: device time of the top-level build */
+    double bvh_refit_seconds;   /* device time of the last rt_scene_refit */
 } RtSceneInfo;
 int rt_scene_info(const RtScene* s, RtSceneInfo* out);
+/* Moving primitives.  The reference has no such path: a changed world is a new BvhNode::new (src/main.rs:531, src/bvh.rs:89-156).
+ * Here spheres and moving spheres of a resident scene are rewritten in place -- ids are object ids in creation order
+ * (rtb_object_count); xyzr = 4 doubles per sphere (centre, radius, src/objects.rs:161); a moving sphere takes 9 doubles
+ * (centre0, centre1, time0, time1, radius, src/objects.rs:266) -- and rt_scene_refit recomputes every box of the scene's trees
+ * bottom-up on the GPU, keeping their shape (boxes as src/objects.rs:241-244, 328-335, 413-429, 514-516 and
+ * src/transrot.rs:34-38, 60-82 define them).  Closest hits after a refit equal those of a scene built from the moved
+ * primitives; only the traversal cost depends on how far things moved.  A primitive that bounds a constant medium cannot be
+ * moved (RT_ERR_UNSUPPORTED).  rt_flat_set_* / rt_flat_refit do the same on a host-only flatten. */
+int rt_scene_set_spheres(RtScene* s, const int32_t* object_ids, int32_t n, const double* xyzr);
+int rt_scene_set_moving_spheres(RtScene* s, const int32_t* object_ids, int32_t n, const double* c0_c1_t0_t1_r);
+int rt_scene_refit(RtScene* s);
+
 /* Host-only flatten (no GPU touched): for inspection and CPU-side checks.  The returned pointer is
  * an RtSceneView (ray_tracing_amd/csrc/rt_types.h) with HOST pointers, valid until rt_flat_destroy. */
 typedef struct RtFlat RtFlat;
@@ -129,6 +142,9 @@ int rt_flat_create_ex(const RtBuilder* b, RtObj world, int flags, RtFlat** out);
 const void* rt_flat_view(const RtFlat* f);
 int rt_flat_info(const RtFlat* f, RtSceneInfo* out);
 void rt_flat_destroy(RtFlat* f);
+int rt_flat_set_spheres(RtFlat* f, const int32_t* object_ids, int32_t n, const double* xyzr);
+int rt_flat_set_moving_spheres(RtFlat* f, const int32_t* object_ids, int32_t n, const double* c0_c1_t0_t1_r);
+int rt_flat_refit(RtFlat* f);
 
 /* ------------------------------------------------------------------ rendering */
 typedef struct RtCamera {                       /* arguments of Camera::new, src/cameras.rs:38-48 */

@@ -41,7 +41,7 @@ class RtSceneInfo(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_nodes", "n_spheres", "n_moving_spheres", "n_rects", "n_instances",
                                          "n_media", "n_materials", "n_textures", "n_perlin", "tlas_depth",
                                          "blas_depth", "max_stack", "n_objects", "device", "n_boxes")] + \
-               [("world_box", C.c_double * 6), ("device_bytes", C.c_uint64), ("bvh_build_seconds", C.c_double)]
+               [("world_box", C.c_double * 6), ("device_bytes", C.c_uint64), ("bvh_build_seconds", C.c_double), ("bvh_refit_seconds", C.c_double)]
 
 
 class RtCamera(C.Structure):
@@ -100,6 +100,12 @@ API = {
     "rt_flat_view": (_P, [_P]),
     "rt_flat_info": (C.c_int, [_P, C.POINTER(RtSceneInfo)]),
     "rt_flat_destroy": (None, [_P]),
+    "rt_flat_set_spheres": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32, _D3]),
+    "rt_flat_set_moving_spheres": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32, _D3]),
+    "rt_flat_refit": (C.c_int, [_P]),
+    "rt_scene_set_spheres": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32, _D3]),
+    "rt_scene_set_moving_spheres": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32, _D3]),
+    "rt_scene_refit": (C.c_int, [_P]),
     "rt_render": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtRenderParams), _P, _P, C.POINTER(RtStats)]),
     "rt_render_device": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtRenderParams), _P, _P, _P, C.POINTER(RtStats)]),
     "rt_render_device_noalloc": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtRenderParams), _P, _P, _P, C.POINTER(RtStats)]),
@@ -279,6 +285,13 @@ def render_params(width, height, spp, max_depth, seed, sample_offset=0, backgrou
     return p
 
 
+def _set_prims(fn, handle, object_ids, values, width):
+    ids = np.ascontiguousarray(object_ids, dtype=np.int32).reshape(-1)
+    vals = np.ascontiguousarray(values, dtype=np.float64).reshape(-1, width)
+    assert vals.shape[0] == ids.shape[0]
+    _check(fn(handle, ids.ctypes.data_as(C.POINTER(C.c_int32)), ids.shape[0], vals.ctypes.data_as(_D3)))
+
+
 def _with_flags(params, flags):
     q = RtRenderParams()
     C.memmove(C.byref(q), C.byref(params), C.sizeof(RtRenderParams))
@@ -329,6 +342,18 @@ class Scene:
         info = RtSceneInfo()
         _check(lib().rt_scene_info(self._h, C.byref(info)))
         return info
+
+    def set_spheres(self, object_ids, xyzr):
+        """Rewrites spheres (by object id, creation order) in place: xyzr[i] = (cx, cy, cz, r).  Call refit() afterwards."""
+        _set_prims(lib().rt_scene_set_spheres, self._h, object_ids, xyzr, 4)
+
+    def set_moving_spheres(self, object_ids, values):
+        """values[i] = (c0 xyz, c1 xyz, time0, time1, radius)."""
+        _set_prims(lib().rt_scene_set_moving_spheres, self._h, object_ids, values, 9)
+
+    def refit(self):
+        """Recomputes every box of the scene's trees on the GPU from the primitives as they are now (the trees keep their shape)."""
+        _check(lib().rt_scene_refit(self._h))
 
     def render(self, cam, params, accum=None, want_sumsq=False):
         """Adds the per-pixel colour sums of params.spp samples to `accum` ([H,W,3] float32).  Returns (accum, sumsq|None, stats)."""

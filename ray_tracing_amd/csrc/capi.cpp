@@ -325,6 +325,24 @@ int rt_write_image(const char* path, const uint8_t* rgb, int32_t w, int32_t h) {
     return rt_set_error(RT_ERR_UNSUPPORTED, "image format '" + ext + "' is not supported (png, jpeg, ppm)");
 }
 
+// ---- moving primitives + refit on the host copy (the CPU-side mirror of rt_scene_set_* / rt_scene_refit)
+static int flat_set(RtFlat* f, int kind, const int32_t* ids, int32_t n, const double* values) {
+    if (!f || n < 0 || (n > 0 && (!ids || !values))) return rt_set_error(RT_ERR_INVALID, "bad argument");
+    if (!f->indexed) { rt::build_prim_index(f->flat, f->of_id); f->indexed = true; }
+    std::vector<int32_t> touched; std::string err;
+    if (!rt::set_prims_host(f->flat, f->of_id, kind, ids, n, values, touched, err)) return rt_set_error(rt_status_of(err), err);
+    return RT_OK;
+}
+int rt_flat_set_spheres(RtFlat* f, const int32_t* ids, int32_t n, const double* xyzr) { return flat_set(f, 0, ids, n, xyzr); }
+int rt_flat_set_moving_spheres(RtFlat* f, const int32_t* ids, int32_t n, const double* values) { return flat_set(f, 1, ids, n, values); }
+int rt_flat_refit(RtFlat* f) {
+    if (!f) return rt_set_error(RT_ERR_INVALID, "null argument");
+    std::string err;
+    if (!rt::refit_host(f->flat, err)) return rt_set_error(RT_ERR_INTERNAL, err);
+    f->view = f->flat.view();
+    return RT_OK;
+}
+
 // ---- accumulator checkpoints: header {magic, width, height, spp_done, seed} then width * height * 3 floats
 static const uint64_t kAccumMagic = 0x314D554343415452ull;  // "RTACCUM1"
 int rt_accum_save(const char* path, const float* accum_rgb, int32_t w, int32_t h, int64_t spp_done, uint64_t seed) {

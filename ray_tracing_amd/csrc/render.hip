@@ -762,6 +762,9 @@ struct RtScene {
     bool shade_fused = false;              // ... and the BVH is a handful of nodes: k_shade_lds<true> finds the closest hits too, k_trace is not run
     RtShadePlan shade_plan;                // k_shade_lds: layout of the block's LDS
     int shade_lds_bytes = 0;
+    const int32_t* d_wsrc = nullptr;       // device copy of flat.wsrc (refit of the wide tree)
+    std::vector<int32_t> of_id[2]; bool indexed = false;   // object id -> sphere / moving-sphere record (rt_scene_set_*)
+    double refit_seconds = 0.0;
     // rt_render_multi: this GPU's private accumulators and stream (grow-only)
     float *multi_acc = nullptr, *multi_sq = nullptr; size_t multi_floats = 0; hipStream_t multi_stream = nullptr;
 };
@@ -1122,6 +1125,7 @@ int rt_scene_create_ex(const RtBuilder* b, RtObj world, int device, int flags, R
         int r;
         if ((r = upload(s, f.wnodes, &v.wnodes))) return r;
         if ((r = upload(s, f.winst_roots, &v.winst_roots))) return r;
+        if ((r = upload(s, f.wsrc, &s->d_wsrc))) return r;
         if (s->nodes_on_device) v.nodes = s->nodes_on_device;
         else if ((r = upload(s, f.nodes, &v.nodes))) return r;
         if ((r = upload(s, f.spheres, &v.spheres))) return r;
@@ -1172,11 +1176,12 @@ static void fill_info(const rt::FlatScene& f, RtSceneInfo* o) {
     o->n_instances = v.n_instances; o->n_media = v.n_media; o->n_materials = v.n_materials; o->n_textures = v.n_textures; o->n_perlin = v.n_perlin;
     o->tlas_depth = f.tlas_depth; o->blas_depth = f.blas_depth; o->max_stack = f.max_stack; o->n_objects = f.n_ids; o->device = -1;
     for (int i = 0; i < 6; ++i) o->world_box[i] = f.world_box[i];
-    o->device_bytes = 0; o->bvh_build_seconds = 0.0;
+    o->device_bytes = 0; o->bvh_build_seconds = 0.0; o->bvh_refit_seconds = 0.0;
 }
 int rt_scene_info(const RtScene* s, RtSceneInfo* out) {
     if (!s || !out) return rt_set_error(RT_ERR_INVALID, "null argument");
     fill_info(s->flat, out); out->device = s->device; out->device_bytes = s->device_bytes; out->bvh_build_seconds = s->bvh_build_seconds;
+    out->bvh_refit_seconds = s->refit_seconds;
     return RT_OK;
 }
 int rt_flat_info(const RtFlat* f, RtSceneInfo* out) {
@@ -1391,6 +1396,38 @@ int rt_render(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* a
     }
     (void)hipFree(d_acc); if (d_sq) (void)hipFree(d_sq);
     return rc;
+}
+
+// ---- moving primitives and refit (the reference rebuilds its BvhNode for a changed world, src/main.rs:531)
+static int scene_set(RtScene* s, int kind, const int32_t* ids, int32_t n, const double* values) {
+    if (!s || n < 0 || (n > 0 && (!ids || !values))) return rt_set_error(RT_ERR_INVALID, "bad argument");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    if (!s->indexed) { rt::build_prim_index(s->flat, s->of_id); s->indexed = true; }
+    std::vector<int32_t> touched; std::string err;
+    if (!rt::set_prims_host(s->flat, s->of_id, kind, ids, n, values, touched, err)) return rt_set_error(rt_status_of(err), err);
+    // a few records: one small copy each; many: the whole array
+    const std::vector<rt_f4>& host = kind == 0 ? s->flat.spheres : s->flat.mspheres;
+    rt_f4* dev = const_cast<rt_f4*>(kind == 0 ? s->view.spheres : s->view.mspheres);
+    const size_t per = kind == 0 ? 1 : 3;
+    if (touched.size() > 64) HIP_TRY(hipMemcpy(dev, host.data(), host.size() * sizeof(rt_f4), hipMemcpyHostToDevice));
+    else for (int32_t rec : touched) HIP_TRY(hipMemcpy(dev + per * (size_t)rec, host.data() + per * (size_t)rec, per * sizeof(rt_f4), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+int rt_scene_set_spheres(RtScene* s, const int32_t* ids, int32_t n, const double* xyzr) { return scene_set(s, 0, ids, n, xyzr); }
+int rt_scene_set_moving_spheres(RtScene* s, const int32_t* ids, int32_t n, const double* values) { return scene_set(s, 1, ids, n, values); }
+int rt_scene_refit(RtScene* s) {
+    if (!s) return rt_set_error(RT_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipDeviceSynchronize());       // no render of this scene may still be reading the trees
+    std::string err;
+    double sec = 0.0;
+    if (!rt::refit_device(s->view, s->d_wsrc, s->view.root, s->flat.tlas_depth + s->flat.blas_depth + 2, &sec, err)) return rt_set_error(RT_ERR_HIP, err);
+    s->refit_seconds = sec;
+    // the host copy follows (it is what rt_scene_info and the launch plans describe)
+    HIP_TRY(hipMemcpy(s->flat.nodes.data(), s->view.nodes, s->flat.nodes.size() * sizeof(rt_f4), hipMemcpyDeviceToHost));
+    if (!s->flat.wnodes.empty()) HIP_TRY(hipMemcpy(s->flat.wnodes.data(), s->view.wnodes, s->flat.wnodes.size() * sizeof(rt_f4), hipMemcpyDeviceToHost));
+    return RT_OK;
 }
 
 int rt_shard_samples(int32_t total_spp, int32_t n_shards, int32_t shard, int32_t* first, int32_t* count) {

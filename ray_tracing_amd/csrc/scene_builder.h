@@ -140,6 +140,7 @@ struct FlatScene {
     std::vector<rt_f4> tlas_items;   // deferred top level (flatten(..., defer_top)): 2 records per item, see lbvh.h
     std::vector<rt_f4> wnodes;       // the 4-wide quantised form of `nodes` (build_wide_bvh)
     std::vector<int32_t> winst_roots;
+    std::vector<int32_t> wsrc;       // per wide node and child slot: the binary node << 1 | which child its box came from, -1 = absent
     int wroot = -1, wmax_stack = 0;
     int root = -1, max_stack = 0, tlas_depth = 0, blas_depth = 0, n_ids = 0;
     double world_box[6] = {0, 0, 0, 0, 0, 0};
@@ -152,6 +153,12 @@ struct FlatScene {
 bool flatten(const Builder& b, HittableObj world, FlatScene& out, std::string& err, bool defer_top = false);
 // Collapses the finished binary tree (nodes, root, instances) into the 4-wide quantised tree (wide_bvh.cpp).
 void build_wide_bvh(FlatScene& f);
+// Moves spheres / moving spheres of a flattened scene (by object id, in creation order) and recomputes the boxes of its trees
+// (refit.h) on the host.  A primitive that bounds a constant medium cannot be moved (the medium record holds a copy of it).
+void build_prim_index(const FlatScene& f, std::vector<int32_t> of_id[2]);
+bool set_prims_host(FlatScene& f, const std::vector<int32_t> of_id[2], int kind, const int32_t* ids, int n, const double* values,
+                    std::vector<int32_t>& touched, std::string& err);
+bool refit_host(FlatScene& f, std::string& err);
 // Builds the deferred top level as a linear BVH on the host, with the per-element steps of lbvh.h in plain loops.
 bool lbvh_finish_host(FlatScene& f, std::string& err);
 // Scene box of the deferred items -> Morton frame.

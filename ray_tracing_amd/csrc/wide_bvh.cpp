@@ -18,19 +18,20 @@
 #include <cstring>
 #include <limits>
 #include "scene_builder.h"
+#include "refit.h"
 
 namespace rt {
 namespace {
 
-struct ChildRef { float lo[3], hi[3]; int32_t code; };   // code: binary-tree child code (>= 0 inner node, < 0 leaf)
+struct ChildRef { float lo[3], hi[3]; int32_t code; int32_t src; };   // code: binary-tree child code (>= 0 inner node, < 0 leaf); src: binary node << 1 | which child
 
 int32_t as_int(float f) { int32_t i; std::memcpy(&i, &f, 4); return i; }
 float as_float(int32_t i) { float f; std::memcpy(&f, &i, 4); return f; }
 
 void children_of(const std::vector<rt_f4>& nodes, int n, ChildRef out[2]) {
     const rt_f4* q = &nodes[(size_t)n * 4];
-    out[0] = ChildRef{{q[0].x, q[0].y, q[0].z}, {q[0].w, q[1].x, q[1].y}, as_int(q[3].x)};
-    out[1] = ChildRef{{q[1].z, q[1].w, q[2].x}, {q[2].y, q[2].z, q[2].w}, as_int(q[3].y)};
+    out[0] = ChildRef{{q[0].x, q[0].y, q[0].z}, {q[0].w, q[1].x, q[1].y}, as_int(q[3].x), n << 1};
+    out[1] = ChildRef{{q[1].z, q[1].w, q[2].x}, {q[2].y, q[2].z, q[2].w}, as_int(q[3].y), n << 1 | 1};
 }
 double area(const ChildRef& c) {
     double d[3] = {(double)c.hi[0] - c.lo[0], (double)c.hi[1] - c.lo[1], (double)c.hi[2] - c.lo[2]};
@@ -47,7 +48,12 @@ static int collapse(FlatScene& f, int root2, int* stack_need) {
     struct Pending { int wide, node2; };
     std::vector<Pending> queue;
     const int first = (int)f.wnodes.size() / 4;
-    auto alloc = [&](int node2) { int w = (int)f.wnodes.size() / 4; f.wnodes.resize(f.wnodes.size() + 4, rt_f4{0, 0, 0, 0}); queue.push_back({w, node2}); return w; };
+    auto alloc = [&](int node2) {
+        int w = (int)f.wnodes.size() / 4;
+        f.wnodes.resize(f.wnodes.size() + 4, rt_f4{0, 0, 0, 0}); f.wsrc.resize(f.wsrc.size() + 4, -1);
+        queue.push_back({w, node2});
+        return w;
+    };
     alloc(root2);
     std::vector<int> need_above;   // per wide node of this tree: sum of (children - 1) over its ancestors
     need_above.push_back(0);
@@ -71,43 +77,17 @@ static int collapse(FlatScene& f, int root2, int* stack_need) {
             c[best] = keep[0];
             if (m == 2) c[n++] = keep[1];
         }
-        // quantisation frame
-        float org[3]; double step[3];
-        for (int a = 0; a < 3; ++a) {
-            float lo = std::numeric_limits<float>::infinity(), hi = -lo;
-            for (int k = 0; k < n; ++k) { lo = std::min(lo, c[k].lo[a]); hi = std::max(hi, c[k].hi[a]); }
-            if (n == 0) { lo = hi = 0.0f; }
-            org[a] = lo;
-            double ext = (double)hi - (double)lo;
-            int e = ext > 0 ? (int)std::ceil(std::log2(ext / 255.0)) : -126;
-            e = std::max(-126, std::min(127, e));
-            while (std::ldexp(255.0, e) < ext && e < 127) ++e;     // log2's rounding must not leave the far plane outside the grid
-            step[a] = std::ldexp(1.0, e);
-        }
-        uint32_t q[6] = {0, 0, 0, 0, 0, 0};   // lo.x lo.y lo.z hi.x hi.y hi.z, child k in byte k
-        int32_t code[4];
-        for (int k = 0; k < 4; ++k) {
-            if (k >= n) {   // absent: an inverted box and a code no traversal enters
-                for (int a = 0; a < 3; ++a) q[a] |= 255u << (8 * k);
-                code[k] = RT_EMPTY_STACK;
-                continue;
-            }
-            for (int a = 0; a < 3; ++a) {
-                double lo = std::floor(((double)c[k].lo[a] - (double)org[a]) / step[a]);
-                double hi = std::ceil(((double)c[k].hi[a] - (double)org[a]) / step[a]);
-                uint32_t ql = (uint32_t)std::max(0.0, std::min(255.0, lo)), qh = (uint32_t)std::max(0.0, std::min(255.0, hi));
-                q[a] |= ql << (8 * k); q[3 + a] |= qh << (8 * k);
-            }
+        RtBox6 boxes[4]; int32_t code[4];
+        for (int k = 0; k < n; ++k) {
+            for (int a = 0; a < 3; ++a) { boxes[k].lo[a] = c[k].lo[a]; boxes[k].hi[a] = c[k].hi[a]; }
             code[k] = c[k].code;
         }
         const int here = need_above[(size_t)(cur.wide - first)] + std::max(0, n - 1);
         need = std::max(need, here);
         for (int k = 0; k < n; ++k) if (code[k] >= 0) { code[k] = alloc(code[k]); need_above.push_back(here); }
-        rt_f4* w = &f.wnodes[(size_t)cur.wide * 4];
-        w[0] = rt_f4{org[0], org[1], org[2], (float)step[0]};
-        w[1] = rt_f4{as_float((int32_t)q[0]), as_float((int32_t)q[1]), as_float((int32_t)q[2]), as_float((int32_t)q[3])};
-        w[2] = rt_f4{as_float((int32_t)q[4]), as_float((int32_t)q[5]), as_float(code[0]), as_float(code[1])};
-        w[3] = rt_f4{as_float(code[2]), as_float(code[3]), (float)step[1], (float)step[2]};
+        rt_f4 w[4];
+        rt_wide_encode(boxes, code, n, w);                  // the same encoder the refit kernels use
+        for (int k = 0; k < 4; ++k) { f.wnodes[(size_t)cur.wide * 4 + k] = w[k]; f.wsrc[(size_t)cur.wide * 4 + k] = k < n ? c[k].src : -1; }
     }
     *stack_need = need;
     return first;
@@ -116,7 +96,7 @@ static int collapse(FlatScene& f, int root2, int* stack_need) {
 // Builds f.wnodes / f.winst_roots / f.wroot / f.wmax_stack from the finished binary tree (top level first, so that its top
 // levels are the first nodes of the array; then every instance's tree).
 void build_wide_bvh(FlatScene& f) {
-    f.wnodes.clear(); f.winst_roots.clear(); f.wroot = -1; f.wmax_stack = 0;
+    f.wnodes.clear(); f.wsrc.clear(); f.winst_roots.clear(); f.wroot = -1; f.wmax_stack = 0;
     if (f.root < 0) return;
     int top_need = 0, blas_need = 0;
     f.wroot = collapse(f, f.root, &top_need);

@@ -231,6 +231,13 @@ class FlatScene:
         rt.lib().rt_flat_info(self.h, C.byref(info))
         return info
 
+    def set_spheres(self, ids, xyzr): rt._set_prims(rt.lib().rt_flat_set_spheres, self.h, ids, xyzr, 4)
+    def set_moving_spheres(self, ids, values): rt._set_prims(rt.lib().rt_flat_set_moving_spheres, self.h, ids, values, 9)
+
+    def refit(self):
+        rt._check(rt.lib().rt_flat_refit(self.h))
+        self.view = rt.lib().rt_flat_view(self.h)
+
 
 def emul_trace_primary(flat, cam, params, sample, want_normal=False, want_uv=False):
     n = params.width * params.height

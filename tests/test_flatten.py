@@ -287,3 +287,83 @@ def test_wide_bvh_traversal_matches_oracle(flags, monkeypatch):
     agree, rel = primary_agreement(wide, o)
     assert agree >= 0.9999 and rel <= 1e-4, (agree, rel)
     assert np.array_equal(wide["id"], plain["id"]) and np.array_equal(wide["t"], plain["t"])     # closest hits do not depend on the tree
+
+
+# ---------------------------------------------------------------------------------------------- moving primitives + refit
+def moving_scene(b, positions, radii, cluster_pos, msphere):
+    """Spheres at `positions`, a rotated and translated cluster of spheres at `cluster_pos` (an instance subtree), one moving
+    sphere and a ground rectangle.  Returns (world, ids of the free spheres, ids of the cluster spheres, id of the moving sphere)."""
+    mats = [b.lambertian((0.5, 0.5, 0.5)), b.metal((0.8, 0.8, 0.8), 0.1), b.dielectric(1.5)]
+    kids, ids, cids = [], [], []
+    for i, (p, r) in enumerate(zip(positions, radii)):
+        ids.append(b.object_count()); kids.append(b.sphere(p, r, mats[i % 3]))
+    inner = []
+    for i, p in enumerate(cluster_pos):
+        cids.append(b.object_count()); inner.append(b.sphere(p, 0.4, mats[i % 3]))
+    kids.append(b.translate(b.rotate_y(b.bvh_node(b.list(inner)), 25.0), (-3.0, 1.0, -12.0)))
+    mid = b.object_count()
+    kids.append(b.moving_sphere(msphere[0:3], msphere[3:6], msphere[6], msphere[7], msphere[8], mats[0]))
+    kids.append(b.rectangle(mats[0], -40, 40, -60, 10, -2.0, rt.RECT_XZ))
+    return b.list(kids), ids, cids, mid
+
+
+@pytest.mark.parametrize("flags", [0, rt.RT_BVH_LINEAR])
+def test_refit_gives_the_hits_of_a_rebuild(flags, monkeypatch):
+    """Move most primitives of a flattened scene (free spheres, spheres inside an instanced subtree, a moving sphere), refit
+    the boxes on the host, and compare the closest hits -- through the binary and through the wide tree -- with a scene
+    flattened from the moved primitives, and with the oracle."""
+    from helpers import OracleBuilder, OracleCamera, RENDER_SEED, emul_trace_primary, oracle_trace_primary, primary_agreement
+    rng = np.random.default_rng(5)
+    n, m = 400, 60
+    pos0 = rng.uniform([-15, -1, -30], [15, 8, -8], (n, 3)); rad = rng.uniform(0.2, 0.9, n)
+    cl0 = rng.uniform(0, 6, (m, 3))
+    ms0 = np.array([4, 5, -10, 6, 6, -10, 0.0, 1.0, 0.8])
+    pos1 = pos0 + rng.normal(0, 1.5, (n, 3)); pos1[::7] = pos0[::7]          # most move, some stay
+    rad1 = rad * rng.uniform(0.7, 1.3, n)
+    cl1 = cl0 + rng.normal(0, 0.8, (m, 3))
+    ms1 = np.array([-6, 4, -12, -3, 7, -11, 0.0, 1.0, 1.1])
+
+    b = rt.Builder()
+    world, ids, cids, mid = moving_scene(b, pos0, rad, cl0, ms0)
+    flat = FlatScene(b, world, flags)
+    flat.set_spheres(ids, np.concatenate([pos1, rad1[:, None]], axis=1))
+    flat.set_spheres(cids, np.concatenate([cl1, np.full((m, 1), 0.4)], axis=1))
+    flat.set_moving_spheres([mid], ms1[None, :])
+    flat.refit()
+
+    b2, ob = rt.Builder(), OracleBuilder()
+    w2, _, _, _ = moving_scene(b2, pos1, rad1, cl1, ms1)
+    ow, _, _, _ = moving_scene(ob, pos1, rad1, cl1, ms1)
+    ob.set_world(ow)
+    fresh = FlatScene(b2, w2, flags)
+    cam = rt.make_camera((0, 6, 12), (0, 2, -18), (0, 1, 0), 45.0, 1.5, 0.05, 20.0)
+    W, H = 180, 120
+    p = rt.render_params(W, H, 1, 50, RENDER_SEED)
+    o = oracle_trace_primary(ob, OracleCamera(cam), W, H, 0, RENDER_SEED)
+    for wide in ("0", "1"):
+        monkeypatch.setenv("EMUL_WIDE_BVH", wide)
+        got, want = emul_trace_primary(flat, cam, p, 0), emul_trace_primary(fresh, cam, p, 0)
+        assert np.array_equal(got["id"], want["id"]) and np.array_equal(got["t"], want["t"])
+        agree, rel = primary_agreement(got, o)
+        assert agree >= 0.9999 and rel <= 1e-4, (wide, agree, rel)
+    assert (o["id"] >= 0).mean() > 0.5
+    # structure: the refitted boxes contain what is below them
+    a = arrays(flat)
+    walk(a, a["root"], set(), 0, dict(depth=0, inst=[]), False)
+
+
+def test_refit_refuses_what_it_cannot_move():
+    b = rt.Builder()
+    m = b.lambertian((0.5, 0.5, 0.5))
+    bound_id = b.object_count()
+    ball = b.sphere((0, 0, -5), 1.0, m)
+    rect_id = b.object_count()
+    world = b.list([b.constant_medium_from_color(ball, 0.5, (1, 1, 1)), b.rectangle(m, -1, 1, -1, 1, -9.0, rt.RECT_XY), b.sphere((3, 0, -5), 1.0, m)])
+    flat = FlatScene(b, world)
+    for bad in (bound_id, rect_id, 9999, -1):
+        with pytest.raises(rt.RtError):
+            flat.set_spheres([bad], [[0, 0, 0, 1]])
+    with pytest.raises(rt.RtError):
+        flat.set_moving_spheres([bound_id + 3], [[0] * 9])           # a sphere is not a moving sphere
+    flat.set_spheres([b.object_count() - 1], [[2, 0, -5, 0.5]])
+    flat.refit()
