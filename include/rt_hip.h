@@ -190,6 +190,12 @@ int rt_render(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* a
 int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* d_accum_rgb, float* d_accum_sq,
                      void* hip_stream, RtStats* stats);
 
+/* The wavefront workspace (ray queues, hit records, contribution slots: 128 bytes per path of a pass, 34 GB for the default pass of
+ * 2^28 paths) belongs to the GPU, not to a scene: all scene handles on one GPU share it, it only grows, and render calls on one GPU
+ * take turns on it (calls on different GPUs run side by side).  rt_release_workspace frees it, e.g. before handing the GPU's memory to
+ * another library; the next render allocates it again.  No counterpart in the reference. */
+int rt_release_workspace(int device);
+
 /* rt_render_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
  * that forbid hipMalloc).  It has no counterpart in the reference.  The ray queues, hit records, contribution slots and counters
  * of a pass live in a static 64 MiB device array that every GPU the library runs on holds until the process ends, so the call

@@ -109,6 +109,7 @@ API = {
     "rt_render": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtRenderParams), _P, _P, C.POINTER(RtStats)]),
     "rt_render_device": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtRenderParams), _P, _P, _P, C.POINTER(RtStats)]),
     "rt_render_device_noalloc": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtRenderParams), _P, _P, _P, C.POINTER(RtStats)]),
+    "rt_release_workspace": (C.c_int, [C.c_int]),
     "rt_render_multi": (C.c_int, [C.POINTER(_P), C.c_int32, C.POINTER(RtCamera), C.POINTER(RtRenderParams), _P, _P, C.POINTER(RtStats)]),
     "rt_shard_samples": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rt_trace_primary": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtRenderParams), C.c_int32, _P, _P, _P, _P, _P]),
@@ -297,6 +298,11 @@ def _with_flags(params, flags):
     C.memmove(C.byref(q), C.byref(params), C.sizeof(RtRenderParams))
     q.flags = flags
     return q
+
+
+def release_workspace(device=0):
+    """Frees the GPU's shared wavefront workspace (queues, hit records, contribution slots); the next render allocates it again."""
+    _check(lib().rt_release_workspace(device))
 
 
 def shard_samples(total_spp, shard, n_shards):

@@ -729,7 +729,8 @@ static __device__ __align__(256) unsigned char g_noalloc_scratch[kNaScratchBytes
 
 // ------------------------------------------------------------------ host side
 // Device memory of one wavefront pass: the two ray queues (three float4 streams each), the hit stream, one contribution slot
-// per path and the counters.  A scene owns a grow-only one (hipMalloc); rt_render_device_noalloc carves a fixed one out of a
+// per path and the counters.  Every GPU has ONE grow-only workspace (hipMalloc) that all scene handles on it share -- a pass of
+// 2^28 paths needs 34 GB, which no caller should pay once per scene -- and rt_render_device_noalloc carves a fixed one out of a
 // static device array instead.
 struct Workspace {
     size_t paths = 0, cap = 0;             // paths it was sized for; slots per queue region
@@ -747,7 +748,6 @@ struct RtScene {
     RtSceneView view;              // device pointers
     std::vector<void*> allocs;     // scene arrays
     uint64_t device_bytes = 0;
-    Workspace ws;                          // render workspace (grow-only)
     unsigned char* static_scratch = nullptr;   // this device's copy of the static scratch array (rt_render_device_noalloc)
     RtTracePlan plan;                      // k_trace: what lives in the block's LDS
     int lds_bytes = 0;                     // k_trace: dynamic LDS size
@@ -966,8 +966,18 @@ static size_t region_cap(size_t n_paths) {
     size_t cap = (n_paths + RT_SHARDS - 1) / RT_SHARDS + (size_t)1024 * (RT_SHARDS + 2);
     return (cap + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK;
 }
-static int ensure_workspace(RtScene* s, size_t n_paths) {
-    Workspace& w = s->ws;
+// The shared workspace of one GPU.  A render call holds `busy` from its first launch until its stream has drained, so two calls on
+// one GPU (two scenes, two host threads) take turns instead of sharing queues; calls on different GPUs never meet.
+struct DeviceWorkspace { std::mutex busy; Workspace ws; };
+static std::mutex g_pool_mutex;
+static std::map<int, DeviceWorkspace*> g_pool;      // by device; entries live until rt_release_workspace or the end of the process
+static DeviceWorkspace* device_workspace(int device) {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    DeviceWorkspace*& d = g_pool[device];
+    if (!d) d = new DeviceWorkspace;
+    return d;
+}
+static int ensure_workspace(RtScene* s, Workspace& w, size_t n_paths) {
     if (!w.counts) {
         w.rows = RT_MAX_BOUNCES + 2;
         HIP_TRY(hipMalloc((void**)&w.counts, (size_t)2 * w.rows * RT_SHARDS * RT_COUNT_STRIDE * sizeof(uint32_t)));
@@ -975,11 +985,13 @@ static int ensure_workspace(RtScene* s, size_t n_paths) {
     }
     if (!w.work) { HIP_TRY(hipMalloc((void**)&w.work, 32 * sizeof(unsigned long long))); }
     if (!s->ev0) { HIP_TRY(hipEventCreate(&s->ev0)); HIP_TRY(hipEventCreate(&s->ev1)); }
-    if (w.paths >= n_paths) return RT_OK;
-    free_queues(w);
     size_t cap = region_cap(n_paths);
     // test hook: a deliberately small region capacity makes the queues overflow, which must be reported, not rendered
-    if (const char* e = std::getenv("RT_DEBUG_QUEUE_CAP")) { long v = std::atol(e); if (v > 0) cap = std::min(cap, ((size_t)v + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK); }
+    bool capped = false;
+    if (const char* e = std::getenv("RT_DEBUG_QUEUE_CAP")) { long v = std::atol(e); if (v > 0) { cap = std::min(cap, ((size_t)v + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK); capped = true; } }
+    if (w.paths >= n_paths && !capped && w.cap >= cap) return RT_OK;
+    if (w.paths >= n_paths && capped) { w.cap = std::min(w.cap, cap); return RT_OK; }   // the hook only ever shrinks what the kernels may use
+    free_queues(w);
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(hipMalloc((void**)&w.qa[i], cap * RT_SHARDS * sizeof(rt_f4)));
         HIP_TRY(hipMalloc((void**)&w.qb[i], cap * RT_SHARDS * sizeof(rt_f4)));
@@ -1157,10 +1169,6 @@ void rt_scene_destroy(RtScene* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     for (void* p : s->allocs) (void)hipFree(p);
-    free_queues(s->ws);
-    if (s->ws.counts) (void)hipFree(s->ws.counts);
-    if (s->ws.folded) (void)hipFree(s->ws.folded);
-    if (s->ws.work) (void)hipFree(s->ws.work);
     if (s->multi_acc) (void)hipFree(s->multi_acc);
     if (s->multi_sq) (void)hipFree(s->multi_sq);
     if (s->multi_stream) (void)hipStreamDestroy(s->multi_stream);
@@ -1322,8 +1330,10 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     chunk_max = std::min(chunk_max, std::max(1, p->spp));
     // The default pass is sized for an otherwise empty 288 GB part; when the workspace does not fit (other tenants, several
     // scene handles) the pass is halved until it does.  An explicit paths_per_pass is taken as given.
-    while ((rc = ensure_workspace(s, (size_t)chunk_max * n_pixels)) == RT_ERR_OOM && p->paths_per_pass <= 0 && chunk_max > 1) {
-        free_queues(s->ws);
+    DeviceWorkspace* pool = device_workspace(s->device);
+    std::lock_guard<std::mutex> turn(pool->busy);
+    while ((rc = ensure_workspace(s, pool->ws, (size_t)chunk_max * n_pixels)) == RT_ERR_OOM && p->paths_per_pass <= 0 && chunk_max > 1) {
+        free_queues(pool->ws);
         (void)hipGetLastError();
         chunk_max = (chunk_max + 1) / 2;
     }
@@ -1332,10 +1342,24 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     local.paths = (uint64_t)n_pixels * (uint64_t)p->spp;
     std::vector<unsigned long long> h_folded((size_t)p->max_depth + 2);
     float* sq = (p->flags & RT_FLAG_SUMSQ) ? d_accum_sq : nullptr;
-    rc = render_passes(s, s->ws, cam, p, chunk_max, d_accum, sq, st, true, h_folded.data(), local);
+    rc = render_passes(s, pool->ws, cam, p, chunk_max, d_accum, sq, st, true, h_folded.data(), local);
     if (rc) return rc;
     local.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     if (stats) *stats = local;
+    return RT_OK;
+}
+
+int rt_release_workspace(int device) {
+    DeviceWorkspace* d = nullptr;
+    { std::lock_guard<std::mutex> lock(g_pool_mutex); auto it = g_pool.find(device); if (it != g_pool.end()) d = it->second; }
+    if (!d) return RT_OK;
+    std::lock_guard<std::mutex> turn(d->busy);
+    HIP_TRY(hipSetDevice(device));
+    free_queues(d->ws);
+    if (d->ws.counts) (void)hipFree(d->ws.counts);
+    if (d->ws.folded) (void)hipFree(d->ws.folded);
+    if (d->ws.work) (void)hipFree(d->ws.work);
+    d->ws = Workspace();
     return RT_OK;
 }
 

@@ -255,3 +255,36 @@ def test_refit_of_the_stress_scene(gpu_required, stress_world):
     assert same.mean() >= ID_AGREEMENT and np.array_equal(got["t"][same], want["t"][same])       # ties between overlapping spheres aside
     print("refit of 1M spheres: %.2f ms on the device" % (scene.info().bvh_refit_seconds * 1e3))
     scene.close(); fresh.close()
+
+
+def test_scenes_on_one_gpu_share_one_workspace(gpu_required):
+    """The queues of a pass belong to the GPU: a second scene handle must not allocate them again, two host threads rendering two
+    scenes on one GPU take turns and each gets its own image, and rt_release_workspace gives the memory back."""
+    import threading
+    import torch
+    cfg_a, cam_a, ba, wa, _ = scene_pair("final_scene.yml")
+    cfg_b, cam_b, bb, wb, _ = scene_pair("cornell.yml")
+    a, b = rt.Scene(ba, wa, 0), rt.Scene(bb, wb, 0)
+    pa = rt.render_params(400, 400, 8, cfg_a.max_depth, RENDER_SEED)
+    pb = rt.render_params(400, 400, 8, cfg_b.max_depth, RENDER_SEED)
+    want_a, _, _ = a.render(cam_a, pa)
+    free_after_first = torch.cuda.mem_get_info(0)[0]
+    want_b, _, _ = b.render(cam_b, pb)
+    assert free_after_first - torch.cuda.mem_get_info(0)[0] < 64 << 20          # same pass size: nothing new but small buffers
+    got = {}
+
+    def run(key, scene, cam, p):
+        for _ in range(3):
+            got[key], _, _ = scene.render(cam, p)
+    ts = [threading.Thread(target=run, args=("a", a, cam_a, pa)), threading.Thread(target=run, args=("b", b, cam_b, pb))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert np.array_equal(got["a"], want_a) and np.array_equal(got["b"], want_b)
+    before = torch.cuda.mem_get_info(0)[0]
+    rt.release_workspace(0)
+    assert torch.cuda.mem_get_info(0)[0] - before > 100 << 20                    # 400 * 400 * 8 paths * 128 B and the region slack
+    again, _, _ = a.render(cam_a, pa)                                            # allocated again on demand
+    assert np.array_equal(again, want_a)
+    a.close(); b.close()
