@@ -66,8 +66,9 @@ struct LdsStack {  // one column of the block's LDS stack: entry i of thread t l
 };
 
 __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev fr, uint32_t n_paths, uint32_t cap, uint32_t* counts1, uint32_t* overflow,
-                                                     rt_f4* qa, rt_f4* qb, rt_f4* qc, rt_f4* contrib) {
-    // Chunks of 256 consecutive path ids are dealt round-robin to the regions.
+                                                     rt_f4* qa, rt_f4* qb, rt_f4* contrib) {
+    // Chunks of 256 consecutive path ids are dealt round-robin to the regions.  A camera ray's third record (throughput 1,
+    // path id) follows from where it sits in the queue (rt_first_c), so it is neither written here nor read by the first bounce.
     if (blockIdx.x == 0 && threadIdx.x < RT_SHARDS) {
         uint32_t n_chunks = (n_paths + RT_BLOCK - 1) / RT_BLOCK, sh = threadIdx.x;
         uint32_t mine = n_chunks / RT_SHARDS + (sh < n_chunks % RT_SHARDS ? 1u : 0u);
@@ -80,10 +81,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev
         rt_split_path(fr, pid, pixel, s);
         v3 o, d; float time;
         rt_camera_ray(cam, fr, pixel, (uint32_t)fr.sample_base + s, o, d, time);
-        rt_f4 a, b, c;
+        rt_f4 a, b;
         a.x = o.x; a.y = o.y; a.z = o.z; a.w = time;
         b.x = d.x; b.y = d.y; b.z = d.z; b.w = i2f((int)RT_HIT_NONE);
-        c.x = 1.0f; c.y = 1.0f; c.z = 1.0f; c.w = i2f((int)pid);
         uint32_t chunk = pid / RT_BLOCK;
         uint32_t in_region = (chunk / RT_SHARDS) * RT_BLOCK + pid % RT_BLOCK;
         *reinterpret_cast<float4*>(contrib + pid) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // the path's light, written where it ends (k_shade)
@@ -91,8 +91,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_raygen(RtCameraDev cam, RtFrameDev
         size_t slot = (size_t)(chunk % RT_SHARDS) * cap + in_region;
         *reinterpret_cast<float4*>(qa + slot) = make_float4(a.x, a.y, a.z, a.w);
         *reinterpret_cast<float4*>(qb + slot) = make_float4(b.x, b.y, b.z, b.w);
-        *reinterpret_cast<float4*>(qc + slot) = make_float4(c.x, c.y, c.z, c.w);
     }
+}
+// The third record of the camera ray at entry i of region `region` of the first bounce's queue: throughput 1 and the path id
+// k_raygen placed there.
+__device__ __forceinline__ rt_f4 rt_first_c(uint32_t region, uint32_t i) {
+    rt_f4 c; c.x = 1.0f; c.y = 1.0f; c.z = 1.0f;
+    c.w = i2f((int)(((i / RT_BLOCK) * RT_SHARDS + region) * RT_BLOCK + i % RT_BLOCK));
+    return c;
 }
 
 // ---- k_trace: closest surface hit of every queued ray
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev f
     // Returns true when the hit was postponed.  Called from wave-uniform control flow only (the append votes over the wave).
     auto shade = [&](uint32_t i, bool valid, bool may_postpone) -> bool {
         ShadeOut out; shade_out_clear(out);
-        if (valid) shade_ray<STATS>(sc, tab, msrc, fr, bounce, ld4(ia + i), ld4(ib + i), ld4(ic + i), ld4(hits + i), may_postpone, contrib, work, out);
+        if (valid) shade_ray<STATS>(sc, tab, msrc, fr, bounce, ld4(ia + i), ld4(ib + i), bounce == 1 ? rt_first_c(blockIdx.y, i) : ld4(ic + i), ld4(hits + i), may_postpone, contrib, work, out);
         shade_append(out, n_out_ptr, overflow, cap, oa, ob, oc);
         return out.postponed;
     };
@@ -515,10 +521,10 @@ __device__ __forceinline__ void shade_stage_one(const rt_f4* src, lds_f4* dst) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0), "v"(src) : "memory");
 }
 template <bool NO_HITS>
-__device__ __forceinline__ void shade_stage(const rt_f4* ia, const rt_f4* ib, const rt_f4* ic, const rt_f4* hits, uint32_t i, lds_f4* stage) {
+__device__ __forceinline__ void shade_stage(const rt_f4* ia, const rt_f4* ib, const rt_f4* ic, const rt_f4* hits, uint32_t i, lds_f4* stage, bool with_c) {
     shade_stage_one(ia + i, stage);
     shade_stage_one(ib + i, stage + 64);
-    shade_stage_one(ic + i, stage + 128);
+    if (with_c) shade_stage_one(ic + i, stage + 128);
     if (!NO_HITS) shade_stage_one(hits + i, stage + 192);
 }
 
@@ -581,7 +587,8 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
         rt_f4 h; h.x = hit.t; h.y = i2f((int)hit.code); h.z = i2f(hit.inst); h.w = 0.0f;
         return h;
     };
-    if (base < n) shade_stage<FUSED>(ia, ib, ic, hits, min(base + lane, n - 1u), stage);
+    const bool with_c = bounce != 1;                                   // camera rays: see rt_first_c
+    if (base < n) shade_stage<FUSED>(ia, ib, ic, hits, min(base + lane, n - 1u), stage, with_c);
     bool landed = false;                                               // the staged records are known to have arrived
     // One loop body, one inlined copy of the shading code: an iteration shades either 64 postponed hits of one class (as soon
     // as a class has that many, and whatever is left once the queue is exhausted) or the wave's next 64 staged queue entries.
@@ -604,19 +611,20 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
             __builtin_amdgcn_wave_barrier();
             valid = lane < cnt; may_post = false;
             i = valid ? later[(uint32_t)flush * 128u + first + lane] : 0u;
-            if (valid) { a = ld4(ia + i); b = ld4(ib + i); c = ld4(ic + i); if (!FUSED) h = ld4(hits + i); }
+            if (valid) { a = ld4(ia + i); b = ld4(ib + i); if (with_c) c = ld4(ic + i); if (!FUSED) h = ld4(hits + i); }
             landed = true;                                             // these loads were issued after the staging and are waited for below
         } else {
             i = base + lane;
             if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            a = lds_ld4(stage + lane); b = lds_ld4(stage + 64 + lane); c = lds_ld4(stage + 128 + lane);
+            a = lds_ld4(stage + lane); b = lds_ld4(stage + 64 + lane); if (with_c) c = lds_ld4(stage + 128 + lane);
             if (!FUSED) h = lds_ld4(stage + 192 + lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the records are in registers, the staging area is free
-            if (base + stride < n) shade_stage<FUSED>(ia, ib, ic, hits, min(i + stride, n - 1u), stage);
+            if (base + stride < n) shade_stage<FUSED>(ia, ib, ic, hits, min(i + stride, n - 1u), stage, with_c);
             valid = i < n; may_post = may_postpone;
             base += stride;
             landed = false;
         }
+        if (!with_c) c = rt_first_c(blockIdx.y, i);
         ShadeOut out; shade_out_clear(out);
         if (valid) {
             if (FUSED) h = closest(a, b);
@@ -1233,7 +1241,7 @@ static int render_passes(RtScene* s, const Workspace& ws, const RtCamera* cam, c
         HIP_TRY(hipMemsetAsync(ws.counts, 0, counts_bytes, st));
         HIP_TRY(hipMemsetAsync(ws.counts + (size_t)ws.rows * row_words, 0, counts_bytes, st));
         int grid = (int)std::min<size_t>(((size_t)n_paths + RT_BLOCK - 1) / RT_BLOCK, (size_t)grid_cap);
-        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, cd, fr, n_paths, cap, ws.counts + row_words, overflow, ws.qa[0], ws.qb[0], ws.qc[0], ws.contrib);
+        hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, cd, fr, n_paths, cap, ws.counts + row_words, overflow, ws.qa[0], ws.qb[0], ws.contrib);
         // bounce grid: x = blocks per region (a multiple of RT_SHARDS, see the capacity argument above), y = region
         int gx = (int)std::min<size_t>(((size_t)n_paths / RT_SHARDS + RT_BLOCK - 1) / RT_BLOCK + 1, (size_t)grid_cap / RT_SHARDS);
         gx = std::max(RT_SHARDS, (gx + RT_SHARDS - 1) / RT_SHARDS * RT_SHARDS);
