@@ -842,8 +842,10 @@ static void fill_plan(const RtSceneView& v, int n_nodes, int max_stack, int thre
 
 // Chooses k_trace's block shape, LDS plan and grid for a scene.
 static int plan_trace(RtScene* s) {
-    int refill = 16;
-    if (const char* e = std::getenv("RT_REFILL_LANES")) refill = std::max(1, std::min(64, std::atoi(e)));
+    // idle lanes that trigger a refill, measured: 24 beats 16 by 1.3 % (final_scene.yml) to 3.6 % (cornell_box.yml) when the scene is in
+    // LDS; the 4-wide kernel's longer steps prefer fuller waves (16)
+    int refill = 24, refill_wide = 16;
+    if (const char* e = std::getenv("RT_REFILL_LANES")) refill = refill_wide = std::max(1, std::min(64, std::atoi(e)));
     const char* env_tb = std::getenv("RT_TRACE_BLOCK");
     const int want = env_tb ? std::atoi(env_tb) : 1024;
     const char* env_w = std::getenv("RT_TRACE_WIDE_STACK"); const bool narrow_ok = !(env_w && std::atoi(env_w) != 0);
@@ -856,7 +858,7 @@ static int plan_trace(RtScene* s) {
         bool want_wide = !s->plan.resident && s->plan.wide_stack;
         if (const char* e = std::getenv("RT_TRACE_BVH4")) want_wide = std::atoi(e) != 0;
         if (want_wide && s->view.n_wnodes > 0 && s->view.wmax_stack * 1024 * 4 + 64 <= kLdsBudget)
-            fill_plan(s->view, s->view.n_wnodes, s->view.wmax_stack, 1024, kLdsBudget, refill, false, true, 0, s->plan, s->lds_bytes);
+            fill_plan(s->view, s->view.n_wnodes, s->view.wmax_stack, 1024, kLdsBudget, refill_wide, false, true, 0, s->plan, s->lds_bytes);
         const void* fns[2];
         if (s->plan.wide4 && s->plan.resident) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, true, true>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, true, true>); }
         else if (s->plan.wide4) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, false, true>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, false, true>); }
