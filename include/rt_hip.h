@@ -208,7 +208,8 @@ int rt_render_device_noalloc(RtScene* s, const RtCamera* cam, const RtRenderPara
                              void* hip_stream, RtStats* stats);
 
 /* Multi-GPU render inside one process: the per-pixel sum of src/main.rs:585-589 lifted across GPUs.  scenes[i] is the same world
- * flattened onto GPU i (one handle per GPU, distinct devices).  The samples [sample_offset, sample_offset + spp) are cut into
+ * flattened onto a GPU (normally one handle per GPU; handles that share a GPU take turns on it and their sums are added on the
+ * device before the reduce).  The samples [sample_offset, sample_offset + spp) are cut into
  * n_scenes contiguous ranges (rt_shard_samples); GPU i renders its range into a private accumulator on its own host thread and
  * stream; one ncclReduce(sum, f32, W*H*3) over RCCL brings them to scenes[0]'s GPU, and the result is ADDED to the host buffers.
  * The Philox counter carries the absolute sample index, so the image equals a one-GPU render up to fp32 summation order; with

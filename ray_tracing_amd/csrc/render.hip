@@ -645,6 +645,11 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
     }
 }
 
+__global__ __launch_bounds__(RT_BLOCK) void k_add_into(float* dst, const float* src, size_t n) {   // rt_render_multi: handles that share a GPU
+    size_t i = (size_t)blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i < n) dst[i] += src[i];
+}
+
 // accum[pixel] += sum over the pass's samples, in sample order (main.rs:585-589).
 __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const rt_f4* contrib, int n_pixels, int spp_chunk, float* accum, float* accum_sq) {
     int pixel = blockIdx.x * RT_BLOCK + threadIdx.x;
@@ -1542,8 +1547,12 @@ int rt_render_multi(RtScene* const* scenes, int32_t n_scenes, const RtCamera* ca
         if (rc) return rc;
         devices[i] = scenes[i]->device;
         for (int j = 0; j < i; ++j)
-            if (devices[j] == devices[i]) return rt_set_error(RT_ERR_INVALID, "rt_render_multi: two scenes on GPU " + std::to_string(devices[i]) + " (one scene handle per GPU)");
+            if (scenes[j] == scenes[i]) return rt_set_error(RT_ERR_INVALID, "rt_render_multi: the same scene handle twice");
     }
+    // Handles may share a GPU (their renders then take turns on its workspace): the first handle of each GPU collects the
+    // others' sums on the device, and only those first handles meet in the reduce.
+    std::vector<int> leader(n);
+    for (int i = 0; i < n; ++i) { leader[i] = i; for (int j = 0; j < i; ++j) if (devices[j] == devices[i]) { leader[i] = j; break; } }
     auto t_begin = std::chrono::steady_clock::now();
     const bool want_sq = (p->flags & RT_FLAG_SUMSQ) != 0;
     const size_t floats = (size_t)p->width * (size_t)p->height * 3;
@@ -1583,14 +1592,24 @@ int rt_render_multi(RtScene* const* scenes, int32_t n_scenes, const RtCamera* ca
         for (auto& t : threads) t.join();
     }
     for (int i = 0; i < n; ++i) if (rcs[i]) return rt_set_error(rcs[i], "GPU " + std::to_string(devices[i]) + ": " + errs[i]);
+    for (int i = 0; i < n; ++i) {
+        if (leader[i] == i) continue;
+        RtScene* to = scenes[leader[i]];
+        HIP_TRY(hipSetDevice(to->device));
+        const unsigned grid = (unsigned)((floats + RT_BLOCK - 1) / RT_BLOCK);
+        hipLaunchKernelGGL(k_add_into, dim3(grid), dim3(RT_BLOCK), 0, to->multi_stream, to->multi_acc, scenes[i]->multi_acc, floats);
+        if (want_sq) hipLaunchKernelGGL(k_add_into, dim3(grid), dim3(RT_BLOCK), 0, to->multi_stream, to->multi_sq, scenes[i]->multi_sq, floats);
+        HIP_TRY(hipGetLastError());
+    }
     // one reduce(SUM) of W*H*3 floats to the first GPU (the per-pixel sum of src/main.rs:585-589 lifted across GPUs)
-    std::vector<float*> bufs(n); std::vector<hipStream_t> streams(n);
-    for (int i = 0; i < n; ++i) { bufs[i] = scenes[i]->multi_acc; streams[i] = scenes[i]->multi_stream; }
-    int rc = rccl_reduce_to_first(devices, bufs, streams, floats);
+    std::vector<int> gpus; std::vector<float*> bufs; std::vector<hipStream_t> streams;
+    for (int i = 0; i < n; ++i) if (leader[i] == i) { gpus.push_back(devices[i]); bufs.push_back(scenes[i]->multi_acc); streams.push_back(scenes[i]->multi_stream); }
+    int rc = rccl_reduce_to_first(gpus, bufs, streams, floats);
     if (rc) return rc;
     if (want_sq) {
-        for (int i = 0; i < n; ++i) bufs[i] = scenes[i]->multi_sq;
-        if ((rc = rccl_reduce_to_first(devices, bufs, streams, floats))) return rc;
+        bufs.clear();
+        for (int i = 0; i < n; ++i) if (leader[i] == i) bufs.push_back(scenes[i]->multi_sq);
+        if ((rc = rccl_reduce_to_first(gpus, bufs, streams, floats))) return rc;
     }
     HIP_TRY(hipSetDevice(devices[0]));
     std::vector<float> tmp(floats);

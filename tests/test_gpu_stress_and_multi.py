@@ -148,7 +148,7 @@ def test_queue_overflow_is_reported_not_rendered(gpu_required):
 
 def test_render_multi_on_one_gpu_equals_render(gpu_required):
     """rt_render_multi with one scene: host thread, private accumulator, the RCCL reduce (a one-rank communicator) and the
-    host add must give rt_render's image bit for bit; two handles on one GPU are refused."""
+    host add must give rt_render's image bit for bit; the same handle twice is refused."""
     cfg, cam, b, world, _ = scene_pair("final_scene.yml")
     scene = rt.Scene(b, world, 0)
     p = rt.render_params(160, 120, 6, cfg.max_depth, RENDER_SEED, sample_offset=3)
@@ -158,11 +158,28 @@ def test_render_multi_on_one_gpu_equals_render(gpu_required):
     assert np.array_equal(got, want) and np.array_equal(got_sq, want_sq)
     again, _, _ = rt.render_multi([scene], cam, p, accum=got.copy())  # adds into the caller's buffer; the communicator is reused
     assert np.array_equal(again, 2 * want)
-    twin = rt.Scene(b, world, 0)
     with pytest.raises(rt.RtError) as e:
-        rt.render_multi([scene, twin], cam, p)
+        rt.render_multi([scene, scene], cam, p)                       # the same handle twice
     assert e.value.code == -1
-    twin.close(); scene.close()
+    scene.close()
+
+
+def test_render_multi_with_three_handles_on_one_gpu(gpu_required):
+    """Everything of rt_render_multi that one GPU can exercise with more than one handle: a host thread per handle, contiguous
+    sample ranges with absolute Philox sample indices, private accumulators, the on-device add of handles that share a GPU and
+    the RCCL reduce of what is left.  7 samples over 3 handles = 3 + 2 + 2; the image equals the one-call render up to the order
+    of the three partial sums, the ray counts exactly."""
+    cfg, cam, b, world, _ = scene_pair("cornell.yml")
+    scenes = [rt.Scene(b, world, 0) for _ in range(3)]
+    p = rt.render_params(120, 96, 7, cfg.max_depth, RENDER_SEED, sample_offset=11)
+    want, want_sq, st = scenes[0].render(cam, p, want_sumsq=True)
+    got, got_sq, st2 = rt.render_multi(scenes, cam, p, want_sumsq=True)
+    assert st2.rays == st.rays and st2.paths == st.paths and list(st2.rays_per_bounce) == list(st.rays_per_bounce)
+    assert np.allclose(got, want, rtol=2e-6, atol=1e-6) and np.allclose(got_sq, want_sq, rtol=2e-6, atol=1e-6)
+    parts = [scenes[0].render(cam, rt.render_params(120, 96, c, cfg.max_depth, RENDER_SEED, sample_offset=11 + f))[0] for f, c in ((0, 3), (3, 2), (5, 2))]
+    assert np.array_equal(got, (parts[0] + parts[1]) + parts[2])     # the shards, added in handle order
+    for s in scenes:
+        s.close()
 
 
 def test_render_sharded_with_the_hip_renderer(gpu_required):
