@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other configs of the metric (cornell.yml, the 1M-sphere scene)")
     ap.add_argument("--stress-spp", type=int, default=32, help="samples per step of the 1M-sphere 3840x2160 run reported under `also`")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N ranks share GPU 0 and talk over gloo: runs the N>1 code path on a one-GPU box; the line is tagged and is not a scaling result")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,11 +128,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run --nproc-per-node N" % (args.gpus, world))
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     if not torch.cuda.is_available() or rt.device_count() <= local_rank:
         raise SystemExit("bench.py needs a GPU per rank; the render path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 and args.rehearse_on_one_gpu:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     def barrier():
@@ -226,6 +232,8 @@ def main():
                              "achieved_gbs": bytes_per_ray * rays0 / b_s / 1e9, "achieved_tflops": flops_per_ray * rays0 / b_s / 1e12},
             "work_per_ray": counts,
         }
+        if args.rehearse_on_one_gpu:
+            out["rehearsal"] = "%d ranks share one GPU and reduce over gloo: a run of the multi-rank code path, not a scaling measurement" % world
     if not args.no_secondary:
         main_run["scene"].close()
         also = {}

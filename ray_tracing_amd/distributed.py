@@ -24,7 +24,13 @@ def reduce_accumulators(accum, dst=0, group=None):
     """Sums the ranks' accumulation buffers into rank `dst` (in place) -- the in-process channel reduce of
     src/main.rs:585-589 lifted across GPUs.  `accum` is a torch tensor on this rank's device."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if accum.is_cuda and dist.get_backend(group) == "gloo":
+            # gloo has no reduce for device tensors (a debugging set-up: several ranks on one GPU, or no RCCL): through the host
+            host = accum.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM, group=group)
+            accum.copy_(host)
+        else:
+            dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return accum
 
 

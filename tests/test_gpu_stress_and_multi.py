@@ -305,3 +305,43 @@ def test_scenes_on_one_gpu_share_one_workspace(gpu_required):
     again, _, _ = a.render(cam_a, pa)                                            # allocated again on demand
     assert np.array_equal(again, want_a)
     a.close(); b.close()
+
+
+def _hip_rank(rank, world_size, port, out_path):
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from ray_tracing_amd.distributed import render_sharded
+        cfg, cam, b, world, _ = scene_pair("cornell_box.yml")
+        scene = rt.Scene(b, world, 0)
+
+        def render_into(accum, first, count):
+            scene.render_device(cam, rt.render_params(96, 96, count, cfg.max_depth, RENDER_SEED, sample_offset=first), accum.data_ptr(), None,
+                                torch.cuda.current_stream().cuda_stream)
+        accum = render_sharded(render_into, 96, 96, 7, torch.device("cuda", 0))
+        if rank == 0:
+            np.save(out_path, accum.cpu().numpy())
+        scene.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_three_ranks_shard_the_hip_renderer(gpu_required, tmp_path):
+    """One process per rank, as bench.py runs under torch.distributed.run, with the HIP renderer in every rank.  The box has one
+    GPU, so the three ranks share it and reduce over gloo (through the host); sharding, absolute sample indices and the reduce to
+    rank 0 are the code the N-GPU run uses.  7 samples = 3 + 2 + 2."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "accum.npy")
+    mp.spawn(_hip_rank, args=(3, port, out), nprocs=3, join=True)
+    got = np.load(out)
+    cfg, cam, b, world, _ = scene_pair("cornell_box.yml")
+    scene = rt.Scene(b, world, 0)
+    want, _, _ = scene.render(cam, rt.render_params(96, 96, 7, cfg.max_depth, RENDER_SEED))
+    assert want.sum() > 0 and np.allclose(got, want, rtol=2e-6, atol=1e-6)
+    scene.close()
