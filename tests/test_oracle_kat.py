@@ -239,6 +239,43 @@ def test_unit_vector_is_unit_and_uniform():  # utils.rs:13-22 (normalised => on 
     assert np.all(np.abs(pts.mean(axis=0)) < 0.05) and np.allclose((pts ** 2).mean(axis=0), 1 / 3, atol=0.03)
 
 
+def test_direct_maps_have_the_distribution_of_the_rejection_loops():
+    """The reference draws its unit vector and its lens point by rejection (utils.rs:13-22: three U[-1,1) until inside the
+    ball, then normalised; cameras.rs:103-113: two U[-1,1) until inside the disk).  The oracle and the kernels use direct maps
+    of two draws; the loops are restated here with numpy and the two samples compared coordinate by coordinate
+    (two-sample Kolmogorov-Smirnov) and through the cap / annulus probabilities."""
+    from scipy import stats
+    rng = np.random.default_rng(2024)
+    n = 20000
+    p = rng.uniform(-1, 1, (4 * n, 3))
+    p = p[(p ** 2).sum(axis=1) < 1.0][:n]
+    ref_sphere = p / np.linalg.norm(p, axis=1, keepdims=True)
+    out = (C.c_double * 3)()
+    mine = []
+    for u1, u2 in rng.random((n, 2)):
+        oracle().orc_unit_vector(u1, u2, out)
+        mine.append(out[:])
+    mine = np.array(mine)
+    for axis in range(3):
+        assert stats.ks_2samp(ref_sphere[:, axis], mine[:, axis]).pvalue > 1e-3
+    assert stats.ks_2samp(np.arctan2(ref_sphere[:, 1], ref_sphere[:, 0]), np.arctan2(mine[:, 1], mine[:, 0])).pvalue > 1e-3
+    # lens: the offset of the camera ray's origin, in units of the lens radius
+    cam = rt.make_camera((0, 0, 0), (0, 0, -1), (0, 1, 0), 40.0, 1.0, 2.0, 1.0)   # aperture 2 -> lens radius 1, u = x, v = y
+    oc = OracleCamera(cam)
+    ray = (C.c_double * 7)()
+    disk = []
+    for s in range(8000):
+        oracle().orc_camera_ray(oc.h, 64, 64, s % 64, (s // 64) % 64, s, RENDER_SEED, ray)
+        disk.append((ray[0], ray[1]))
+    disk = np.array(disk)
+    q = rng.uniform(-1, 1, (4 * 8000, 2))
+    ref_disk = q[(q ** 2).sum(axis=1) < 1.0][:8000]
+    assert np.all((disk ** 2).sum(axis=1) < 1.0)
+    for axis in range(2):
+        assert stats.ks_2samp(ref_disk[:, axis], disk[:, axis]).pvalue > 1e-3
+    assert stats.ks_2samp((ref_disk ** 2).sum(axis=1), (disk ** 2).sum(axis=1)).pvalue > 1e-3    # r^2 uniform on [0, 1)
+
+
 def test_scatter_rules():  # materials.rs:77-90, 129-145, 181-209, 243-249
     L = oracle()
     out = (C.c_double * 13)()
