@@ -210,6 +210,7 @@ def main():
             "config": {"workload": "%s: %dx%d, max_depth %d, %d spp per step per GPU (scene seed 0x%X, Philox render seed 0x%X)"
                                    % (args.workload, cfg.image_width, cfg.image_height, cfg.max_depth, args.spp_per_step, SCENE_SEED, RENDER_SEED),
                        "paths_per_step": paths, "rays_per_path": main_run["total_rays"] / args.steps / paths,
+                       "mpaths_per_s": paths * args.steps / main_run["dt"] / 1e6,
                        "parallelism": "sample-sharded x%d, reduce(SUM) to rank 0" % world, "image_mean": main_run["mean"]},
             # HBM line of the dominant kernel: the bytes that cross HBM (ray record in, hit record out), measured launch time
             "roofline": {"kernel": kname, "bound": "hbm", "achieved": gbs_hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs_hbm / HBM_PEAK_GBS,
