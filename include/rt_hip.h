@@ -160,10 +160,24 @@ typedef struct RtRenderParams {
     uint64_t seed;              /* Philox key; (pixel, sample, bounce) is the counter */
     int32_t paths_per_pass;     /* 0 = default; paths in flight per wavefront pass */
     int32_t flags;              /* RT_FLAG_* */
+    /* The pixels this call renders -- the reference's outer loops run over all of them (src/main.rs:567-568).  tile = (x0, y0, w, h),
+     * a rectangle of the image (row 0 = top row); all zero = the whole image.  stripe = (band_rows, n_shards, shard): of the
+     * rectangle's rows keep only the bands of `band_rows` rows that a round-robin deal gives to shard `shard` of `n_shards`; all
+     * zero = every row.  The Philox counter holds the pixel's index in the whole image, so the pixels rendered are bit-identical to
+     * those of a whole-image call; the others are left untouched.  The buffers are always those of the whole image. */
+    int32_t tile[4];
+    int32_t stripe[3];
+    int32_t reserved_;          /* 0 */
 } RtRenderParams;
 #define RT_FLAG_SUMSQ 1         /* also accumulate per-channel sum of squares (accum_sq must be given) */
 #define RT_FLAG_COUNTERS 2      /* run the instrumented (slower) kernel build and fill RtStats.work */
 #define RT_FLAG_TIME_TRACE 4    /* bracket every closest-hit launch with HIP events and fill RtStats.kernel_ms_trace */
+#define RT_FLAG_WAVEFRONT_PRIMARY 8 /* rt_trace_primary only: find the hits with the kernels a render of this scene runs at its first
+                                     * bounce (camera rays through the ray queue into the scene's closest-hit kernel) instead of the
+                                     * plain per-ray search */
+#define RT_FLAG_TILES 16        /* rt_render_multi only: shard the PIXELS (row bands of RT_TILE_ROWS rows dealt round-robin), every GPU
+                                 * tracing all samples of its pixels, instead of the samples; chosen automatically when spp < n_scenes */
+#define RT_TILE_ROWS 8
 
 typedef struct RtStats {
     uint64_t rays;              /* ray segments = executions of src/lib.rs:63 */
@@ -179,6 +193,9 @@ typedef struct RtStats {
     uint64_t work[16];
     double kernel_ms_trace;     /* RT_FLAG_TIME_TRACE only: summed device time of the closest-hit kernel alone */
     uint64_t trace_launches;
+    /* rt_render_multi only: distinct GPUs that rendered; ranks of the RCCL communicator that carried the reduce (0: no reduce was
+     * needed -- one GPU, or pixel sharding); 1 when the pixels were sharded (RT_FLAG_TILES), 0 when the samples were */
+    int32_t multi_gpus, multi_comm_ranks, multi_tiles, reserved_;
 } RtStats;
 
 /* Renders `spp` samples of every pixel and ADDS the per-pixel colour sums (src/main.rs:585-589) to
@@ -218,6 +235,15 @@ int rt_render_multi(RtScene* const* scenes, int32_t n_scenes, const RtCamera* ca
                     float* accum_sq, RtStats* stats);
 /* The sample range of shard `shard` of `n_shards`: contiguous, balanced, first shards take the remainder. */
 int rt_shard_samples(int32_t total_spp, int32_t n_shards, int32_t shard, int32_t* first, int32_t* count);
+/* Pixel sharding (the reference's outer loops are over pixels, src/main.rs:567-568): sets p->tile / p->stripe to shard `shard` of
+ * `n_shards` of the image p->width x p->height -- row bands of RT_TILE_ROWS rows dealt round-robin, so that every shard sees the
+ * whole height of the image -- and returns the shard's pixel count in *n_pixels (may be NULL; 0 when there are fewer bands
+ * than shards).  The shards are disjoint and cover the image; a render of each into its own zeroed buffer sums to the whole image
+ * bit for bit. */
+int rt_shard_tiles(RtRenderParams* p, int32_t n_shards, int32_t shard, int64_t* n_pixels);
+/* Destroys the RCCL communicators rt_render_multi has created (they are kept between calls, one set per ordered GPU list).  Call
+ * it when no rt_render_multi is running, e.g. before the process ends.  No counterpart in the reference. */
+int rt_multi_shutdown(void);
 
 /* Parity hook: closest hit of sample `sample` of every pixel (camera ray + src/lib.rs:63).
  * object_id = creation-order id of the primitive / medium hit, -1 on a miss; t = +inf on a miss.

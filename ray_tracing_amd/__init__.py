@@ -18,6 +18,9 @@ _lib = None
 RT_FLAG_SUMSQ = 1
 RT_FLAG_COUNTERS = 2
 RT_FLAG_TIME_TRACE = 4
+RT_FLAG_WAVEFRONT_PRIMARY = 8   # rt_trace_primary through the kernels a render runs (ray queue + the scene's closest-hit kernel)
+RT_FLAG_TILES = 16              # rt_render_multi: shard pixels (row bands) instead of samples
+RT_TILE_ROWS = 8
 RT_BVH_LINEAR = 1            # rt_scene_create_ex / rt_flat_create_ex: linear top-level BVH (built on the GPU for a Scene)
 RECT_XY, RECT_XZ, RECT_YZ = 0, 1, 2   # RectangleType, src/objects.rs:339-343
 
@@ -53,13 +56,15 @@ class RtCamera(C.Structure):
 class RtRenderParams(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("sample_offset", C.c_int32),
                 ("max_depth", C.c_int32), ("background", C.c_float * 3), ("seed", C.c_uint64),
-                ("paths_per_pass", C.c_int32), ("flags", C.c_int32)]
+                ("paths_per_pass", C.c_int32), ("flags", C.c_int32), ("tile", C.c_int32 * 4), ("stripe", C.c_int32 * 3),
+                ("reserved_", C.c_int32)]
 
 
 class RtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("rays_per_bounce", C.c_uint64 * 64),
                 ("seconds", C.c_double), ("kernel_ms_extend", C.c_double), ("extend_launches", C.c_uint64),
-                ("passes", C.c_int32), ("work", C.c_uint64 * 16), ("kernel_ms_trace", C.c_double), ("trace_launches", C.c_uint64)]
+                ("passes", C.c_int32), ("work", C.c_uint64 * 16), ("kernel_ms_trace", C.c_double), ("trace_launches", C.c_uint64),
+                ("multi_gpus", C.c_int32), ("multi_comm_ranks", C.c_int32), ("multi_tiles", C.c_int32), ("reserved_", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/rt_hip.h declares
@@ -112,6 +117,8 @@ API = {
     "rt_release_workspace": (C.c_int, [C.c_int]),
     "rt_render_multi": (C.c_int, [C.POINTER(_P), C.c_int32, C.POINTER(RtCamera), C.POINTER(RtRenderParams), _P, _P, C.POINTER(RtStats)]),
     "rt_shard_samples": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "rt_shard_tiles": (C.c_int, [C.POINTER(RtRenderParams), C.c_int32, C.c_int32, C.POINTER(C.c_int64)]),
+    "rt_multi_shutdown": (C.c_int, []),
     "rt_trace_primary": (C.c_int, [_P, C.POINTER(RtCamera), C.POINTER(RtRenderParams), C.c_int32, _P, _P, _P, _P, _P]),
     "rt_scatter_rays": (C.c_int, [_P, _P, C.c_int32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint64, _P]),
     "rt_tonemap_u8": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
@@ -278,12 +285,30 @@ def make_camera(look_from, look_at, v_up, vfov, aspect, aperture, focus_dist, sh
 
 
 def render_params(width, height, spp, max_depth, seed, sample_offset=0, background=(0.0, 0.0, 0.0),
-                  paths_per_pass=0, flags=0):
+                  paths_per_pass=0, flags=0, tile=None, stripe=None):
+    """tile = (x0, y0, w, h) and stripe = (band_rows, n_shards, shard) select the pixels rendered (None: all)."""
     p = RtRenderParams()
     p.width, p.height, p.spp, p.sample_offset, p.max_depth = width, height, spp, sample_offset, max_depth
     p.background[0], p.background[1], p.background[2] = background
     p.seed, p.paths_per_pass, p.flags = seed, paths_per_pass, flags
+    if tile is not None:
+        p.tile[0], p.tile[1], p.tile[2], p.tile[3] = tile
+    if stripe is not None:
+        p.stripe[0], p.stripe[1], p.stripe[2] = stripe
     return p
+
+
+def shard_tiles(params, shard, n_shards):
+    """A copy of `params` that renders pixel shard `shard` of `n_shards` (rt_shard_tiles), and the shard's pixel count."""
+    q = _with_flags(params, params.flags)
+    n = C.c_int64(0)
+    _check(lib().rt_shard_tiles(C.byref(q), n_shards, shard, C.byref(n)))
+    return q, n.value
+
+
+def multi_shutdown():
+    """Destroys the RCCL communicators kept by render_multi."""
+    _check(lib().rt_multi_shutdown())
 
 
 def _set_prims(fn, handle, object_ids, values, width):
@@ -390,7 +415,11 @@ class Scene:
                                               C.byref(st) if want_stats else None))
         return st
 
-    def trace_primary(self, cam, params, sample=0, want_normal=False, want_uv=False):
+    def trace_primary(self, cam, params, sample=0, want_normal=False, want_uv=False, wavefront=False):
+        """Closest hit of one sample per pixel.  wavefront=True: through the ray queue and the closest-hit kernel a render of
+        this scene launches (RT_FLAG_WAVEFRONT_PRIMARY) instead of the plain per-ray search."""
+        if wavefront:
+            params = _with_flags(params, params.flags | RT_FLAG_WAVEFRONT_PRIMARY)
         n = params.width * params.height
         ids = np.empty(n, dtype=np.int32)
         t = np.empty(n, dtype=np.float32)

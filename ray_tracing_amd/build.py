@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librt_hip.so")
 CLI = os.path.join(HERE, "rt_cli")
 SOURCES = ["render.hip", "lbvh.hip", "lbvh_host.cpp", "refit.hip", "refit_host.cpp", "capi.cpp", "scene_builder.cpp", "flatten.cpp", "wide_bvh.cpp", "config.cpp"]
-HEADERS = ["rt_types.h", "rt_device.h", "lbvh.h", "refit.h", "scene_builder.h", "capi_internal.h", "../../include/rt_hip.h"]
+HEADERS = ["rt_types.h", "rt_device.h", "frame.h", "lbvh.h", "refit.h", "scene_builder.h", "capi_internal.h", "../../include/rt_hip.h"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function", "-ffp-contract=off"]
 
 

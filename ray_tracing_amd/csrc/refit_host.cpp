@@ -44,17 +44,23 @@ void build_prim_index(const FlatScene& f, std::vector<int32_t> of_id[2]) {
 bool set_prims_host(FlatScene& f, const std::vector<int32_t> of_id[2], int kind, const int32_t* ids, int n, const double* values,
                     std::vector<int32_t>& touched, std::string& err) {
     touched.clear();
+    // every id and value is checked before any record is written, so that a failing call changes nothing
+    std::vector<int32_t> recs((size_t)n);
     for (int j = 0; j < n; ++j) {
         int id = ids[j];
         int32_t rec = (id >= 0 && id < (int)of_id[kind].size()) ? of_id[kind][(size_t)id] : -1;
         if (rec == -2) { err = "flatten: object " + std::to_string(id) + " bounds a constant medium and cannot be moved"; return false; }
         if (rec < 0) { err = "object " + std::to_string(id) + " is not a " + (kind == 0 ? "sphere" : "moving sphere") + " of this scene"; return false; }
+        if (kind == 1 && !(values[9 * (size_t)j + 7] != values[9 * (size_t)j + 6])) { err = "moving sphere with time0 == time1"; return false; }
+        recs[(size_t)j] = rec;
+    }
+    for (int j = 0; j < n; ++j) {
+        const int32_t rec = recs[(size_t)j];
         if (kind == 0) {
             const double* v = values + 4 * (size_t)j;
             f.spheres[(size_t)rec] = rt_f4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
         } else {
             const double* v = values + 9 * (size_t)j;
-            if (!(v[7] != v[6])) { err = "moving sphere with time0 == time1"; return false; }
             f.mspheres[3 * (size_t)rec] = rt_f4{(float)v[0], (float)v[1], (float)v[2], (float)v[8]};
             f.mspheres[3 * (size_t)rec + 1] = rt_f4{(float)(v[3] - v[0]), (float)(v[4] - v[1]), (float)(v[5] - v[2]), (float)v[6]};
             f.mspheres[3 * (size_t)rec + 2] = rt_f4{(float)(1.0 / (v[7] - v[6])), 0, 0, 0};

@@ -24,11 +24,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 #include "capi_internal.h"
+#include "frame.h"
 #include "rt_device.h"
 
 #define RT_BLOCK 256
@@ -534,7 +536,9 @@ __device__ __forceinline__ void shade_stage(const rt_f4* ia, const rt_f4* ib, co
 // nothing when an append happened in between (it waited for all earlier memory operations already).
 // FUSED (scenes of a handful of nodes): the closest hit is found here too, by the plain per-ray traversal over the node
 // array in LDS, and no closest-hit kernel runs: the hit record never exists in memory and the ray record is read once.
-template <bool FUSED>
+// PROBE (FUSED only; the parity hook rt_trace_primary with RT_FLAG_WAVEFRONT_PRIMARY): the hit record found here is also written
+// to `hits`, which a render never does.
+template <bool FUSED, bool PROBE = false>
 __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan pl, RtFrameDev fr, int bounce, uint32_t cap, const uint32_t* counts_in,
                                                     uint32_t* counts_out, uint32_t* overflow, const rt_f4* ia, const rt_f4* ib, const rt_f4* ic,
                                                     const rt_f4* hits, rt_f4* oa, rt_f4* ob, rt_f4* oc, rt_f4* contrib) {
@@ -628,6 +632,7 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
         ShadeOut out; shade_out_clear(out);
         if (valid) {
             if (FUSED) h = closest(a, b);
+            if (FUSED && PROBE) *reinterpret_cast<float4*>(const_cast<rt_f4*>(hits) + i) = make_float4(h.x, h.y, h.z, h.w);
             shade_ray<false>(sc, tab, tab, fr, bounce, a, b, c, h, may_post, contrib, nullptr, out);
         }
         if (shade_append(out, n_out_ptr, overflow, cap, oa, ob, oc)) landed = true;
@@ -650,16 +655,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_add_into(float* dst, const float* 
     if (i < n) dst[i] += src[i];
 }
 
-// accum[pixel] += sum over the pass's samples, in sample order (main.rs:585-589).
-__global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const rt_f4* contrib, int n_pixels, int spp_chunk, float* accum, float* accum_sq) {
-    int pixel = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (pixel >= n_pixels) return;
+// accum[pixel] += sum over the pass's samples, in sample order (main.rs:585-589), for every pixel of the pass's set.
+__global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const rt_f4* contrib, RtFrameDev fr, int spp_chunk, float* accum, float* accum_sq) {
+    int k = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (k >= fr.n_set) return;
     float sx = 0, sy = 0, sz = 0, qx = 0, qy = 0, qz = 0;
     for (int s = 0; s < spp_chunk; ++s) {
-        rt_f4 c = ld4(contrib + (size_t)s * n_pixels + pixel);
+        rt_f4 c = ld4(contrib + (size_t)s * fr.n_set + k);
         sx += c.x; sy += c.y; sz += c.z;
         qx = fmaf(c.x, c.x, qx); qy = fmaf(c.y, c.y, qy); qz = fmaf(c.z, c.z, qz);
     }
+    const uint32_t pixel = rt_set_pixel(fr, (uint32_t)k);
     accum[3 * (size_t)pixel] += sx; accum[3 * (size_t)pixel + 1] += sy; accum[3 * (size_t)pixel + 2] += sz;
     if (accum_sq) { accum_sq[3 * (size_t)pixel] += qx; accum_sq[3 * (size_t)pixel + 1] += qy; accum_sq[3 * (size_t)pixel + 2] += qz; }
 }
@@ -696,6 +702,34 @@ __global__ __launch_bounds__(RT_BLOCK) void k_primary(RtSceneView sc, RtCameraDe
     if (normals) { normals[3 * pixel] = sf.n.x; normals[3 * pixel + 1] = sf.n.y; normals[3 * pixel + 2] = sf.n.z; }
     if (fronts) fronts[pixel] = sf.front ? 1 : 0;
     if (uvs) { uvs[2 * pixel] = sf.u; uvs[2 * pixel + 1] = sf.v; }
+}
+
+// Parity hook, second half of the wavefront form: the camera rays sit in the first bounce's queue (k_raygen) and their hit records
+// are those the scene's closest-hit kernel wrote; media, hit record and the outputs as in k_primary.
+__global__ __launch_bounds__(RT_BLOCK) void k_primary_finish(RtSceneView sc, RtFrameDev fr, uint32_t sample, uint32_t cap, const uint32_t* counts1,
+                                                             const rt_f4* qa, const rt_f4* qb, const rt_f4* hits, int32_t* ids, float* ts, float* normals,
+                                                             int32_t* fronts, float* uvs) {
+    const uint32_t region = blockIdx.y;
+    const uint32_t n = min(counts1[region * RT_COUNT_STRIDE], cap);
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < n; i += gridDim.x * RT_BLOCK) {
+        const size_t slot = (size_t)region * cap + i;
+        const rt_f4 a = ld4(qa + slot), b = ld4(qb + slot), h = ld4(hits + slot);
+        uint32_t pixel, s_local;
+        rt_split_path(fr, (uint32_t)f2i(rt_first_c(region, i).w), pixel, s_local);
+        const v3 o = mk3(a.x, a.y, a.z), d = mk3(b.x, b.y, b.z); const float time = a.w;
+        RtHit hit; hit.t = h.x; hit.code = (uint32_t)f2i(h.y); hit.inst = f2i(h.z);
+        if (sc.n_media > 0) {
+            uint32_t rnd[4];
+            rt_philox(pixel, sample, 1u, 0u, fr.key0, fr.key1, rnd);
+            rt_media_hits(sc, o, d, time, RT_TMIN, pixel, sample, 1u, fr.key0, fr.key1, rnd, hit);
+        }
+        RtSurface sf; sf.id = -1; sf.n = mk3(0, 0, 0); sf.front = false; sf.u = sf.v = 0.0f;
+        if (hit.code != RT_HIT_NONE) rt_surface(sc, o, d, time, hit, true, sf);
+        ids[pixel] = sf.id; ts[pixel] = hit.t;
+        if (normals) { normals[3 * pixel] = sf.n.x; normals[3 * pixel + 1] = sf.n.y; normals[3 * pixel + 2] = sf.n.z; }
+        if (fronts) fronts[pixel] = sf.front ? 1 : 0;
+        if (uvs) { uvs[2 * pixel] = sf.u; uvs[2 * pixel + 1] = sf.v; }
+    }
 }
 
 // Parity hook: one scatter event per explicit ray.
@@ -780,6 +814,7 @@ struct RtScene {
     double refit_seconds = 0.0;
     // rt_render_multi: this GPU's private accumulators and stream (grow-only)
     float *multi_acc = nullptr, *multi_sq = nullptr; size_t multi_floats = 0; hipStream_t multi_stream = nullptr;
+    bool counted = false;                  // this handle is in its device's DeviceWorkspace::handles
 };
 
 static const int kLdsBudget = 160 * 1024 - 512;   // dynamic LDS a 1024-thread block may ask for (one block per CU)
@@ -913,7 +948,8 @@ static int plan_shade(RtScene* s) {
     place((long)v.n_perlin * (RT_PERLIN_PERM_BYTES / 16), pl.off_perlin_perm);
     if (used * 16 > kLdsBudget || s->n_cu < RT_SHARDS) return RT_OK;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade_lds<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget) != hipSuccess) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade_lds<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_shade_lds<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget) != hipSuccess) {
         (void)hipGetLastError();   // this device does not give one workgroup that much LDS
         return RT_OK;
     }
@@ -983,7 +1019,7 @@ static size_t region_cap(size_t n_paths) {
 }
 // The shared workspace of one GPU.  A render call holds `busy` from its first launch until its stream has drained, so two calls on
 // one GPU (two scenes, two host threads) take turns instead of sharing queues; calls on different GPUs never meet.
-struct DeviceWorkspace { std::mutex busy; Workspace ws; };
+struct DeviceWorkspace { std::mutex busy; Workspace ws; int handles = 0; };   // handles: scene handles alive on the device
 static std::mutex g_pool_mutex;
 static std::map<int, DeviceWorkspace*> g_pool;      // by device; entries live until rt_release_workspace or the end of the process
 static DeviceWorkspace* device_workspace(int device) {
@@ -1037,18 +1073,13 @@ static int check_common(const RtScene* s, const RtCamera* cam, const RtRenderPar
     if ((uint64_t)p->width * (uint64_t)p->height > 0x7FFFFFFFull / 4) return rt_set_error(RT_ERR_INVALID, "image too large");
     if (p->max_depth < 0 || p->max_depth > RT_MAX_BOUNCES) return rt_set_error(RT_ERR_INVALID, "max_depth out of range");
     if (s->flat.max_stack > RT_STACK_DEPTH) return rt_set_error(RT_ERR_UNSUPPORTED, "BVH deeper than the traversal stack");
+    if (const char* why = rt_frame_check(p)) return rt_set_error(RT_ERR_INVALID, why);
     return RT_OK;
 }
 
-static void make_frame(const RtRenderParams* p, RtFrameDev& fr) {
-    std::memset(&fr, 0, sizeof(fr));
-    fr.width = p->width; fr.height = p->height; fr.n_pixels = p->width * p->height;
-    fr.max_depth = p->max_depth;
-    fr.key0 = (uint32_t)p->seed; fr.key1 = (uint32_t)(p->seed >> 32);
-    fr.inv_wm1 = (float)(1.0 / (double)(p->width - 1)); fr.inv_hm1 = (float)(1.0 / (double)(p->height - 1));
-    fr.inv_n_pixels = 1.0 / (double)fr.n_pixels;
-    for (int c = 0; c < 3; ++c) fr.background[c] = p->background[c];
-}
+static void make_frame(const RtRenderParams* p, RtFrameDev& fr) { rt_make_frame(p, fr); }
+// Pixels a call with these parameters renders (the whole image, or its tile / stripe selection).
+static size_t set_pixels(const RtRenderParams* p) { RtFrameDev fr; rt_make_frame(p, fr); return (size_t)fr.n_set; }
 static void make_cam(const RtCamera* cam, RtCameraDev& cd) {
     rt::CameraDesc d;
     d.look_from = rt::vec3(cam->look_from[0], cam->look_from[1], cam->look_from[2]);
@@ -1175,6 +1206,7 @@ int rt_scene_create_ex(const RtBuilder* b, RtObj world, int device, int flags, R
         return RT_OK;
     }();
     if (rc != RT_OK) { rt_scene_destroy(s); return rc; }
+    { DeviceWorkspace* d = device_workspace(device); std::lock_guard<std::mutex> lock(g_pool_mutex); d->handles++; s->counted = true; }
     *out = s;
     return RT_OK;
 }
@@ -1190,7 +1222,13 @@ void rt_scene_destroy(RtScene* s) {
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     for (hipEvent_t e : s->ev_trace) (void)hipEventDestroy(e);
+    // the last handle on a GPU takes the shared workspace with it (34 GB for a default pass: a caller that closes its scenes and
+    // hands the GPU to another library must get the memory back)
+    bool last = false;
+    if (s->counted) { DeviceWorkspace* d = device_workspace(s->device); std::lock_guard<std::mutex> lock(g_pool_mutex); last = --d->handles == 0; }
+    const int device = s->device;
     delete s;
+    if (last) (void)rt_release_workspace(device);
 }
 
 static void fill_info(const rt::FlatScene& f, RtSceneInfo* o) {
@@ -1223,7 +1261,8 @@ static int render_passes(RtScene* s, const Workspace& ws, const RtCamera* cam, c
                          hipStream_t st, bool use_events, unsigned long long* h_folded, RtStats& local) {
     RtCameraDev cd; make_cam(cam, cd);
     RtFrameDev fr; make_frame(p, fr);
-    const size_t n_pixels = (size_t)fr.n_pixels;
+    const size_t n_pixels = (size_t)fr.n_set;     // pixels of the call's set
+    if (n_pixels == 0) return RT_OK;              // a shard without rows
     const size_t row_words = (size_t)RT_SHARDS * RT_COUNT_STRIDE;
     const size_t counts_bytes = (size_t)(p->max_depth + 2) * row_words * sizeof(uint32_t);
     uint32_t* overflow = ws.counts;                                  // word 0 of row 0
@@ -1282,7 +1321,7 @@ static int render_passes(RtScene* s, const Workspace& ws, const RtCamera* cam, c
         HIP_TRY(hipGetLastError());
         if (use_events) HIP_TRY(hipEventRecord(s->ev1, st));
         int agrid = (int)((n_pixels + RT_BLOCK - 1) / RT_BLOCK);
-        hipLaunchKernelGGL(k_accumulate, dim3(agrid), dim3(RT_BLOCK), 0, st, ws.contrib, (int)n_pixels, chunk, d_accum, sq);
+        hipLaunchKernelGGL(k_accumulate, dim3(agrid), dim3(RT_BLOCK), 0, st, ws.contrib, fr, chunk, d_accum, sq);
         HIP_TRY(hipGetLastError());
         local.passes++;
         done += chunk;
@@ -1335,7 +1374,7 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     hipStream_t st = (hipStream_t)hip_stream;
     HIP_TRY(hipSetDevice(s->device));
     auto t_begin = std::chrono::steady_clock::now();
-    const size_t n_pixels = (size_t)p->width * (size_t)p->height;
+    const size_t n_pixels = std::max<size_t>(1, set_pixels(p));
     // Default pass: up to 2^28 paths in flight (34 GB of queues, hit and contribution slots on a 288 GB part).  Late
     // bounces hold few rays per launch and run below the bulk rate; the more paths share a pass, the less that costs
     // (final_scene.yml: +10 % from 2^26 to 2^28).
@@ -1354,7 +1393,7 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     }
     if (rc) return rc;
     RtStats local; std::memset(&local, 0, sizeof(local));
-    local.paths = (uint64_t)n_pixels * (uint64_t)p->spp;
+    local.paths = (uint64_t)set_pixels(p) * (uint64_t)p->spp;
     std::vector<unsigned long long> h_folded((size_t)p->max_depth + 2);
     float* sq = (p->flags & RT_FLAG_SUMSQ) ? d_accum_sq : nullptr;
     rc = render_passes(s, pool->ws, cam, p, chunk_max, d_accum, sq, st, true, h_folded.data(), local);
@@ -1385,9 +1424,9 @@ int rt_render_device_noalloc(RtScene* s, const RtCamera* cam, const RtRenderPara
     if (p->spp < 0) return rt_set_error(RT_ERR_INVALID, "spp must be >= 0");
     if ((p->flags & RT_FLAG_SUMSQ) && !d_accum_sq) return rt_set_error(RT_ERR_INVALID, "RT_FLAG_SUMSQ needs accum_sq");
     if (p->flags & ~RT_FLAG_SUMSQ) return rt_set_error(RT_ERR_INVALID, "rt_render_device_noalloc: only RT_FLAG_SUMSQ is supported (counters and timing need allocations)");
-    const size_t n_pixels = (size_t)p->width * (size_t)p->height;
+    const size_t n_pixels = std::max<size_t>(1, set_pixels(p));
     if (n_pixels > RT_NOALLOC_MAX_PATHS)
-        return rt_set_error(RT_ERR_INVALID, "rt_render_device_noalloc: width * height = " + std::to_string(n_pixels) + " exceeds the static workspace of " +
+        return rt_set_error(RT_ERR_INVALID, "rt_render_device_noalloc: the call renders " + std::to_string(n_pixels) + " pixels, which exceeds the static workspace of " +
                                                 std::to_string(RT_NOALLOC_MAX_PATHS) + " paths per pass; use rt_render_device");
     if (p->max_depth > RT_NOALLOC_MAX_DEPTH)
         return rt_set_error(RT_ERR_INVALID, "rt_render_device_noalloc: max_depth exceeds " + std::to_string(RT_NOALLOC_MAX_DEPTH) + "; use rt_render_device");
@@ -1400,7 +1439,7 @@ int rt_render_device_noalloc(RtScene* s, const RtCamera* cam, const RtRenderPara
     chunk_max = std::min(chunk_max, std::max(1, p->spp));
     const Workspace ws = static_workspace(s->static_scratch);
     RtStats local; std::memset(&local, 0, sizeof(local));
-    local.paths = (uint64_t)n_pixels * (uint64_t)p->spp;
+    local.paths = (uint64_t)set_pixels(p) * (uint64_t)p->spp;
     unsigned long long h_folded[RT_NOALLOC_MAX_DEPTH + 2];
     float* sq = (p->flags & RT_FLAG_SUMSQ) ? d_accum_sq : nullptr;
     rc = render_passes(s, ws, cam, p, chunk_max, d_accum, sq, st, false, stats ? h_folded : nullptr, local);
@@ -1486,10 +1525,14 @@ struct RcclApi {
     void* handle = nullptr;
     decltype(&ncclCommInitAll) CommInitAll = nullptr; decltype(&ncclCommDestroy) CommDestroy = nullptr; decltype(&ncclReduce) Reduce = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr; decltype(&ncclGroupEnd) GroupEnd = nullptr; decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
 };
-std::mutex g_rccl_mutex;
+// One communicator per GPU of an ordered device list, kept until rt_multi_shutdown.  `use` serialises the calls that enqueue on
+// the set (RCCL wants one caller at a time per communicator); calls on other sets do not wait for it.
+struct CommSet { std::mutex use; std::vector<ncclComm_t> comms; };
+std::mutex g_rccl_mutex;            // guards g_rccl and g_rccl_comms (held only to look a set up or to create it)
 RcclApi g_rccl;
-std::map<std::vector<int>, std::vector<ncclComm_t>> g_rccl_comms;   // one communicator set per ordered device list, kept until the process ends
+std::map<std::vector<int>, std::shared_ptr<CommSet>> g_rccl_comms;
 
 int rccl_load() {   // g_rccl_mutex held
     if (g_rccl.handle) return RT_OK;
@@ -1501,6 +1544,7 @@ int rccl_load() {   // g_rccl_mutex held
         if (!api.field) return rt_set_error(RT_ERR_NCCL, std::string("librccl lacks ") + name); } while (0)
     RT_SYM(CommInitAll, "ncclCommInitAll"); RT_SYM(CommDestroy, "ncclCommDestroy"); RT_SYM(Reduce, "ncclReduce");
     RT_SYM(GroupStart, "ncclGroupStart"); RT_SYM(GroupEnd, "ncclGroupEnd"); RT_SYM(GetErrorString, "ncclGetErrorString");
+    RT_SYM(CommCount, "ncclCommCount");
 #undef RT_SYM
     g_rccl = api;
     return RT_OK;
@@ -1511,29 +1555,67 @@ int rccl_load() {   // g_rccl_mutex held
         if (r_ != ncclSuccess) return rt_set_error(RT_ERR_NCCL, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
     } while (0)
 
-// sum over the GPUs of `bufs[i]` (count floats each, on stream streams[i] of device devices[i]) into bufs[0]
-int rccl_reduce_to_first(const std::vector<int>& devices, const std::vector<float*>& bufs, const std::vector<hipStream_t>& streams, size_t count) {
-    std::lock_guard<std::mutex> lock(g_rccl_mutex);
-    int rc = rccl_load();
-    if (rc) return rc;
-    auto it = g_rccl_comms.find(devices);
-    if (it == g_rccl_comms.end()) {
-        std::vector<ncclComm_t> comms(devices.size());
-        NCCL_TRY(g_rccl.CommInitAll(comms.data(), (int)devices.size(), devices.data()));
-        it = g_rccl_comms.emplace(devices, comms).first;
+// sum over the GPUs of `bufs[i]` (count floats each, on stream streams[i] of device devices[i]) into bufs[0]; *ranks receives the
+// size of the communicator that carried it
+int rccl_reduce_to_first(const std::vector<int>& devices, const std::vector<float*>& bufs, const std::vector<hipStream_t>& streams, size_t count, int* ranks) {
+    std::shared_ptr<CommSet> set;
+    {
+        std::lock_guard<std::mutex> lock(g_rccl_mutex);
+        int rc = rccl_load();
+        if (rc) return rc;
+        auto it = g_rccl_comms.find(devices);
+        if (it == g_rccl_comms.end()) {
+            auto fresh = std::make_shared<CommSet>();
+            fresh->comms.assign(devices.size(), nullptr);
+            NCCL_TRY(g_rccl.CommInitAll(fresh->comms.data(), (int)devices.size(), devices.data()));   // all or nothing: on failure no communicator exists
+            it = g_rccl_comms.emplace(devices, fresh).first;
+        }
+        set = it->second;
     }
-    NCCL_TRY(g_rccl.GroupStart());
-    for (size_t i = 0; i < devices.size(); ++i) {
-        HIP_TRY(hipSetDevice(devices[i]));
-        NCCL_TRY(g_rccl.Reduce(bufs[i], bufs[i], count, ncclFloat32, ncclSum, 0, it->second[i], streams[i]));
+    {
+        std::lock_guard<std::mutex> turn(set->use);
+        int n_ranks = 0;
+        NCCL_TRY(g_rccl.CommCount(set->comms[0], &n_ranks));
+        if (n_ranks != (int)devices.size()) return rt_set_error(RT_ERR_NCCL, "the communicator has " + std::to_string(n_ranks) + " ranks for " + std::to_string(devices.size()) + " GPUs");
+        if (ranks) *ranks = n_ranks;
+        NCCL_TRY(g_rccl.GroupStart());
+        for (size_t i = 0; i < devices.size(); ++i) {
+            HIP_TRY(hipSetDevice(devices[i]));
+            NCCL_TRY(g_rccl.Reduce(bufs[i], bufs[i], count, ncclFloat32, ncclSum, 0, set->comms[i], streams[i]));
+        }
+        NCCL_TRY(g_rccl.GroupEnd());
     }
-    NCCL_TRY(g_rccl.GroupEnd());
     for (size_t i = 0; i < devices.size(); ++i) { HIP_TRY(hipSetDevice(devices[i])); HIP_TRY(hipStreamSynchronize(streams[i])); }
     return RT_OK;
 }
 }  // namespace
 
 extern "C" {
+
+int rt_multi_shutdown(void) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    int rc = RT_OK;
+    for (auto& kv : g_rccl_comms) {
+        std::lock_guard<std::mutex> turn(kv.second->use);
+        for (size_t i = 0; i < kv.second->comms.size(); ++i) {
+            if (!kv.second->comms[i]) continue;
+            (void)hipSetDevice(kv.first[i]);
+            ncclResult_t r = g_rccl.CommDestroy(kv.second->comms[i]);
+            if (r != ncclSuccess && rc == RT_OK) rc = rt_set_error(RT_ERR_NCCL, std::string("ncclCommDestroy: ") + g_rccl.GetErrorString(r));
+            kv.second->comms[i] = nullptr;
+        }
+    }
+    g_rccl_comms.clear();
+    return rc;
+}
+
+int rt_shard_tiles(RtRenderParams* p, int32_t n_shards, int32_t shard, int64_t* n_pixels) {
+    if (!p || p->width < 1 || p->height < 1 || n_shards < 1 || shard < 0 || shard >= n_shards) return rt_set_error(RT_ERR_INVALID, "rt_shard_tiles: bad argument");
+    std::memset(p->tile, 0, sizeof(p->tile));
+    p->stripe[0] = RT_TILE_ROWS; p->stripe[1] = n_shards; p->stripe[2] = shard;
+    if (n_pixels) *n_pixels = rt_stripe_rows(p->height, RT_TILE_ROWS, n_shards, shard) * (int64_t)p->width;
+    return RT_OK;
+}
 
 int rt_render_multi(RtScene* const* scenes, int32_t n_scenes, const RtCamera* cam, const RtRenderParams* p, float* accum, float* accum_sq, RtStats* stats) {
     if (!scenes || n_scenes < 1 || n_scenes > 64) return rt_set_error(RT_ERR_INVALID, "rt_render_multi: need 1..64 scenes");
@@ -1549,6 +1631,10 @@ int rt_render_multi(RtScene* const* scenes, int32_t n_scenes, const RtCamera* ca
         for (int j = 0; j < i; ++j)
             if (scenes[j] == scenes[i]) return rt_set_error(RT_ERR_INVALID, "rt_render_multi: the same scene handle twice");
     }
+    // Pixel sharding when asked for, and when there are fewer samples than handles (a preview of one sample could otherwise use one
+    // GPU only): every handle then traces all samples of its row bands, the private accumulators are disjoint and no reduce is needed.
+    const bool tiles = (p->flags & RT_FLAG_TILES) != 0 || (p->spp > 0 && p->spp < n);
+    if (tiles && (p->stripe[0] | p->stripe[1] | p->stripe[2]) != 0) return rt_set_error(RT_ERR_INVALID, "rt_render_multi: a call that already selects a stripe cannot be sharded by pixels");
     // Handles may share a GPU (their renders then take turns on its workspace): the first handle of each GPU collects the
     // others' sums on the device, and only those first handles meet in the reduce.
     std::vector<int> leader(n);
@@ -1566,23 +1652,31 @@ int rt_render_multi(RtScene* const* scenes, int32_t n_scenes, const RtCamera* ca
             if (s->multi_sq) (void)hipFree(s->multi_sq);
             s->multi_acc = s->multi_sq = nullptr; s->multi_floats = 0;
             HIP_TRY(hipMalloc((void**)&s->multi_acc, floats * sizeof(float)));
-            HIP_TRY(hipMalloc((void**)&s->multi_sq, floats * sizeof(float)));
             s->multi_floats = floats;
         }
+        if (want_sq && !s->multi_sq) HIP_TRY(hipMalloc((void**)&s->multi_sq, s->multi_floats * sizeof(float)));
         HIP_TRY(hipMemsetAsync(s->multi_acc, 0, floats * sizeof(float), s->multi_stream));
         if (want_sq) HIP_TRY(hipMemsetAsync(s->multi_sq, 0, floats * sizeof(float), s->multi_stream));
     }
-    // GPU i renders its contiguous sample range on its own host thread (rt_render_device synchronises its stream)
+    // GPU i renders its share -- a contiguous sample range, or a pixel shard -- on its own host thread (rt_render_device synchronises
+    // its stream)
     std::vector<RtStats> st(n);
     std::vector<int> rcs(n, RT_OK);
     std::vector<std::string> errs(n);
+    std::vector<RtRenderParams> shard_params(n, *p);
+    for (int i = 0; i < n; ++i) {
+        RtRenderParams& pi = shard_params[i];
+        pi.flags &= ~RT_FLAG_TILES;
+        if (tiles) { pi.stripe[0] = RT_TILE_ROWS; pi.stripe[1] = n; pi.stripe[2] = i; }     // the rows of the caller's tile, or of the image
+        else {
+            int32_t first = 0, count = 0;
+            rt_shard_samples(p->spp, n, i, &first, &count);
+            pi.spp = count; pi.sample_offset = p->sample_offset + first;
+        }
+    }
     auto work = [&](int i) {
-        RtRenderParams pi = *p;
-        int32_t first = 0, count = 0;
-        rt_shard_samples(p->spp, n, i, &first, &count);
-        pi.spp = count; pi.sample_offset = p->sample_offset + first;
         std::memset(&st[i], 0, sizeof(RtStats));
-        rcs[i] = rt_render_device(scenes[i], cam, &pi, scenes[i]->multi_acc, want_sq ? scenes[i]->multi_sq : nullptr, scenes[i]->multi_stream, &st[i]);
+        rcs[i] = rt_render_device(scenes[i], cam, &shard_params[i], scenes[i]->multi_acc, want_sq ? scenes[i]->multi_sq : nullptr, scenes[i]->multi_stream, &st[i]);
         if (rcs[i]) errs[i] = g_rt_error;
     };
     {
@@ -1592,32 +1686,65 @@ int rt_render_multi(RtScene* const* scenes, int32_t n_scenes, const RtCamera* ca
         for (auto& t : threads) t.join();
     }
     for (int i = 0; i < n; ++i) if (rcs[i]) return rt_set_error(rcs[i], "GPU " + std::to_string(devices[i]) + ": " + errs[i]);
-    for (int i = 0; i < n; ++i) {
-        if (leader[i] == i) continue;
-        RtScene* to = scenes[leader[i]];
-        HIP_TRY(hipSetDevice(to->device));
-        const unsigned grid = (unsigned)((floats + RT_BLOCK - 1) / RT_BLOCK);
-        hipLaunchKernelGGL(k_add_into, dim3(grid), dim3(RT_BLOCK), 0, to->multi_stream, to->multi_acc, scenes[i]->multi_acc, floats);
-        if (want_sq) hipLaunchKernelGGL(k_add_into, dim3(grid), dim3(RT_BLOCK), 0, to->multi_stream, to->multi_sq, scenes[i]->multi_sq, floats);
-        HIP_TRY(hipGetLastError());
-    }
-    // one reduce(SUM) of W*H*3 floats to the first GPU (the per-pixel sum of src/main.rs:585-589 lifted across GPUs)
-    std::vector<int> gpus; std::vector<float*> bufs; std::vector<hipStream_t> streams;
-    for (int i = 0; i < n; ++i) if (leader[i] == i) { gpus.push_back(devices[i]); bufs.push_back(scenes[i]->multi_acc); streams.push_back(scenes[i]->multi_stream); }
-    int rc = rccl_reduce_to_first(gpus, bufs, streams, floats);
-    if (rc) return rc;
-    if (want_sq) {
-        bufs.clear();
-        for (int i = 0; i < n; ++i) if (leader[i] == i) bufs.push_back(scenes[i]->multi_sq);
-        if ((rc = rccl_reduce_to_first(gpus, bufs, streams, floats))) return rc;
-    }
-    HIP_TRY(hipSetDevice(devices[0]));
+    // a handle whose share was empty enqueued nothing after its memsets and was never synchronised: its buffers must be complete
+    // before another stream reads them
+    for (int i = 0; i < n; ++i) { HIP_TRY(hipSetDevice(devices[i])); HIP_TRY(hipStreamSynchronize(scenes[i]->multi_stream)); }
+    std::vector<int> gpus;
+    for (int i = 0; i < n; ++i) if (leader[i] == i) gpus.push_back(devices[i]);
+    int comm_ranks = 0;
     std::vector<float> tmp(floats);
-    HIP_TRY(hipMemcpy(tmp.data(), scenes[0]->multi_acc, floats * sizeof(float), hipMemcpyDeviceToHost));
-    for (size_t k = 0; k < floats; ++k) accum[k] += tmp[k];
-    if (want_sq) {
-        HIP_TRY(hipMemcpy(tmp.data(), scenes[0]->multi_sq, floats * sizeof(float), hipMemcpyDeviceToHost));
-        for (size_t k = 0; k < floats; ++k) accum_sq[k] += tmp[k];
+    if (tiles) {
+        // disjoint rows: every handle hands over the bands it rendered, nothing is summed across handles
+        auto gather = [&](bool sq, float* dst) -> int {
+            const int y0 = (p->tile[2] > 0) ? p->tile[1] : 0, rows = (p->tile[2] > 0) ? p->tile[3] : p->height;
+            const size_t row_floats = (size_t)p->width * 3;
+            for (int i = 0; i < n; ++i) {
+                HIP_TRY(hipSetDevice(devices[i]));
+                const float* src = sq ? scenes[i]->multi_sq : scenes[i]->multi_acc;
+                for (int band = i; band * RT_TILE_ROWS < rows; band += n) {
+                    const int r0 = band * RT_TILE_ROWS, nr = std::min(RT_TILE_ROWS, rows - r0);
+                    const size_t off = (size_t)(y0 + r0) * row_floats, cnt = (size_t)nr * row_floats;
+                    HIP_TRY(hipMemcpy(tmp.data() + off, src + off, cnt * sizeof(float), hipMemcpyDeviceToHost));
+                    for (size_t k = off; k < off + cnt; ++k) dst[k] += tmp[k];
+                }
+            }
+            return RT_OK;
+        };
+        int rc = gather(false, accum);
+        if (rc == RT_OK && want_sq) rc = gather(true, accum_sq);
+        if (rc) return rc;
+    } else {
+        for (int i = 0; i < n; ++i) {
+            if (leader[i] == i) continue;
+            RtScene* to = scenes[leader[i]];
+            HIP_TRY(hipSetDevice(to->device));
+            const unsigned grid = (unsigned)((floats + RT_BLOCK - 1) / RT_BLOCK);
+            hipLaunchKernelGGL(k_add_into, dim3(grid), dim3(RT_BLOCK), 0, to->multi_stream, to->multi_acc, scenes[i]->multi_acc, floats);
+            if (want_sq) hipLaunchKernelGGL(k_add_into, dim3(grid), dim3(RT_BLOCK), 0, to->multi_stream, to->multi_sq, scenes[i]->multi_sq, floats);
+            HIP_TRY(hipGetLastError());
+        }
+        // one reduce(SUM) of W*H*3 floats to the first GPU (the per-pixel sum of src/main.rs:585-589 lifted across GPUs); with one
+        // GPU there is nothing to reduce and librccl is not needed (RT_MULTI_FORCE_RCCL=1 runs the one-rank reduce anyway)
+        const char* force = std::getenv("RT_MULTI_FORCE_RCCL");
+        if (gpus.size() > 1 || (force && std::atoi(force) != 0)) {
+            std::vector<float*> bufs; std::vector<hipStream_t> streams;
+            for (int i = 0; i < n; ++i) if (leader[i] == i) { bufs.push_back(scenes[i]->multi_acc); streams.push_back(scenes[i]->multi_stream); }
+            int rc = rccl_reduce_to_first(gpus, bufs, streams, floats, &comm_ranks);
+            if (rc) return rc;
+            if (want_sq) {
+                bufs.clear();
+                for (int i = 0; i < n; ++i) if (leader[i] == i) bufs.push_back(scenes[i]->multi_sq);
+                if ((rc = rccl_reduce_to_first(gpus, bufs, streams, floats, &comm_ranks))) return rc;
+            }
+        }
+        HIP_TRY(hipSetDevice(devices[0]));
+        HIP_TRY(hipStreamSynchronize(scenes[0]->multi_stream));
+        HIP_TRY(hipMemcpy(tmp.data(), scenes[0]->multi_acc, floats * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < floats; ++k) accum[k] += tmp[k];
+        if (want_sq) {
+            HIP_TRY(hipMemcpy(tmp.data(), scenes[0]->multi_sq, floats * sizeof(float), hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < floats; ++k) accum_sq[k] += tmp[k];
+        }
     }
     if (stats) {
         RtStats tot; std::memset(&tot, 0, sizeof(tot));
@@ -1630,6 +1757,7 @@ int rt_render_multi(RtScene* const* scenes, int32_t n_scenes, const RtCamera* ca
             for (int k = 0; k < 16; ++k) tot.work[k] += st[i].work[k];
         }
         tot.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        tot.multi_gpus = (int32_t)gpus.size(); tot.multi_comm_ranks = comm_ranks; tot.multi_tiles = tiles ? 1 : 0;
         *stats = tot;
     }
     return RT_OK;
@@ -1642,7 +1770,9 @@ int rt_trace_primary(RtScene* s, const RtCamera* cam, const RtRenderParams* p, i
     if (!ids || !ts) return rt_set_error(RT_ERR_INVALID, "null output buffer");
     HIP_TRY(hipSetDevice(s->device));
     RtCameraDev cd; make_cam(cam, cd);
-    RtFrameDev fr; make_frame(p, fr);
+    RtRenderParams whole = *p;                                      // the hook always covers the whole image
+    std::memset(whole.tile, 0, sizeof(whole.tile)); std::memset(whole.stripe, 0, sizeof(whole.stripe));
+    RtFrameDev fr; make_frame(&whole, fr);
     size_t n = (size_t)fr.n_pixels;
     int32_t *d_ids = nullptr, *d_fr = nullptr; float *d_t = nullptr, *d_n = nullptr, *d_uv = nullptr;
     auto cleanup = [&]() { (void)hipFree(d_ids); (void)hipFree(d_t); if (d_n) (void)hipFree(d_n); if (d_fr) (void)hipFree(d_fr); if (d_uv) (void)hipFree(d_uv); };
@@ -1652,7 +1782,40 @@ int rt_trace_primary(RtScene* s, const RtCamera* cam, const RtRenderParams* p, i
         if (fronts) HIP_TRY(hipMalloc((void**)&d_fr, n * 4));
         if (uvs) HIP_TRY(hipMalloc((void**)&d_uv, n * 8));
         int grid = (int)((n + RT_BLOCK - 1) / RT_BLOCK);
-        hipLaunchKernelGGL(k_primary, dim3(grid), dim3(RT_BLOCK), 0, 0, s->view, cd, fr, (uint32_t)sample, d_ids, d_t, d_n, d_fr, d_uv);
+        if (p->flags & RT_FLAG_WAVEFRONT_PRIMARY) {
+            // The first bounce of a one-sample pass as render_passes launches it: camera rays into the queue, then the closest-hit
+            // kernel this scene's renders use (k_trace in the form plan_trace chose, or the fused shading kernel's own search).
+            DeviceWorkspace* pool = device_workspace(s->device);
+            std::lock_guard<std::mutex> turn(pool->busy);
+            int r = ensure_workspace(s, pool->ws, n);
+            if (r) return r;
+            const Workspace& ws = pool->ws;
+            const uint32_t cap = (uint32_t)ws.cap;
+            const size_t row_words = (size_t)RT_SHARDS * RT_COUNT_STRIDE;
+            const size_t counts_bytes = 3 * row_words * sizeof(uint32_t);
+            fr.spp_chunk = 1; fr.sample_base = sample;
+            HIP_TRY(hipMemsetAsync(ws.counts, 0, counts_bytes, 0));
+            HIP_TRY(hipMemsetAsync(ws.counts + (size_t)ws.rows * row_words, 0, counts_bytes, 0));
+            const int grid_cap = std::max(1, s->n_cu) * 32;
+            hipLaunchKernelGGL(k_raygen, dim3(std::min(grid, grid_cap)), dim3(RT_BLOCK), 0, 0, cd, fr, (uint32_t)n, cap, ws.counts + row_words, ws.counts, ws.qa[0], ws.qb[0],
+                               ws.contrib);
+            const uint32_t* cin = ws.counts + row_words;
+            if (s->shade_fused) {
+                dim3 lgrid((unsigned)std::max(RT_SHARDS, s->n_cu / RT_SHARDS / RT_SHARDS * RT_SHARDS), RT_SHARDS);
+                hipLaunchKernelGGL((k_shade_lds<true, true>), lgrid, dim3(1024), (size_t)s->shade_lds_bytes, 0, s->view, s->shade_plan, fr, 1, cap, cin,
+                                   ws.counts + 2 * row_words, ws.counts, ws.qa[0], ws.qb[0], ws.qc[0], ws.hits, ws.qa[1], ws.qb[1], ws.qc[1], ws.contrib);
+            } else
+                launch_trace(s, ws, false, 0, cap, cin, ws.counts + (size_t)(ws.rows + 1) * row_words, ws.qa[0], ws.qb[0]);
+            dim3 fgrid((unsigned)std::max<size_t>(1, std::min<size_t>((n / RT_SHARDS + RT_BLOCK - 1) / RT_BLOCK + 1, 4096)), RT_SHARDS);
+            hipLaunchKernelGGL(k_primary_finish, fgrid, dim3(RT_BLOCK), 0, 0, s->view, fr, (uint32_t)sample, cap, cin, ws.qa[0], ws.qb[0], ws.hits, d_ids, d_t, d_n, d_fr,
+                               d_uv);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipDeviceSynchronize());
+            uint32_t overflowed = 0;
+            HIP_TRY(hipMemcpy(&overflowed, ws.counts, sizeof(uint32_t), hipMemcpyDeviceToHost));
+            if (overflowed) return rt_set_error(RT_ERR_INTERNAL, "ray queue overflow in rt_trace_primary");
+        } else
+            hipLaunchKernelGGL(k_primary, dim3(grid), dim3(RT_BLOCK), 0, 0, s->view, cd, fr, (uint32_t)sample, d_ids, d_t, d_n, d_fr, d_uv);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(ids, d_ids, n * 4, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(ts, d_t, n * 4, hipMemcpyDeviceToHost));

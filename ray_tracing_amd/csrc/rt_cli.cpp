@@ -1,6 +1,9 @@
 // rt_cli.cpp -- command-line driver with the flags of the reference binary (main.rs:496-504):
 //   rt_cli -c <config.yml> [-o <image.jpeg|.png|.ppm>]   (default ./image.jpeg, main.rs:502)  plus  --spp N  --seed N  --scene-seed N  --device N  --background r,g,b
-//                                                       --checkpoint <file>  --pass-spp N
+//                                                       --checkpoint <file>  --pass-spp N  --devices a,b,...  --tiles
+// --devices 0,1,...: the scene is flattened onto every listed GPU and each render call is rt_render_multi (samples sharded
+// across the GPUs and reduced over RCCL; --tiles shards the pixels instead, as the call does by itself when a pass has fewer
+// samples than GPUs).  A GPU may be listed more than once: its handles then take turns on it.
 // It does what main() does (main.rs:506-601) with the render loop replaced by rt_render: read the
 // config, build the scene, render samples_per_pixel samples, tonemap (utils.rs:49-63), save.
 // The output format follows the extension (main.rs:600); the 8-bit values are the ones the reference
@@ -35,6 +38,7 @@ int main(int argc, char** argv) {
     long long pass_spp = 1024;
     long long spp_override = -1; unsigned long long seed = 0x5EED0002ull, scene_seed = 0x5EED0001ull; int device = 0;
     float bg[3] = {0, 0, 0}; bool bg_given = false;
+    std::vector<int> devices; bool tiles = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&](const char* flag) -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "rt_cli: %s needs a value\n", flag); std::exit(2); } return argv[++i]; };
@@ -44,10 +48,22 @@ int main(int argc, char** argv) {
         else if (a == "--seed") seed = std::strtoull(next("--seed"), nullptr, 0);
         else if (a == "--scene-seed") scene_seed = std::strtoull(next("--scene-seed"), nullptr, 0);
         else if (a == "--device") device = std::atoi(next("--device"));
+        else if (a == "--devices") {
+            for (const char* q = next("--devices"); *q;) {
+                char* end = nullptr;
+                long v = std::strtol(q, &end, 10);
+                if (end == q || v < 0) { std::fprintf(stderr, "rt_cli: --devices a,b,...\n"); return 2; }
+                devices.push_back((int)v);
+                q = *end == ',' ? end + 1 : end;
+                if (*end != ',' && *end != 0) { std::fprintf(stderr, "rt_cli: --devices a,b,...\n"); return 2; }
+            }
+            if (devices.empty()) { std::fprintf(stderr, "rt_cli: --devices a,b,...\n"); return 2; }
+        }
+        else if (a == "--tiles") tiles = true;
         else if (a == "--checkpoint") checkpoint = next("--checkpoint");
         else if (a == "--pass-spp") pass_spp = std::max(1LL, std::atoll(next("--pass-spp")));
         else if (a == "--background") { if (std::sscanf(next("--background"), "%f,%f,%f", &bg[0], &bg[1], &bg[2]) != 3) { std::fprintf(stderr, "rt_cli: --background r,g,b\n"); return 2; } bg_given = true; }
-        else { std::fprintf(stderr, "usage: rt_cli -c <config.yml> [-o <image.jpeg|.png|.ppm>] [--spp N] [--seed N] [--scene-seed N] [--device N] [--background r,g,b] [--checkpoint <file>] [--pass-spp N]\n"); return 2; }
+        else { std::fprintf(stderr, "usage: rt_cli -c <config.yml> [-o <image.jpeg|.png|.ppm>] [--spp N] [--seed N] [--scene-seed N] [--device N] [--background r,g,b] [--checkpoint <file>] [--pass-spp N] [--devices a,b,...] [--tiles]\n"); return 2; }
     }
     if (config.empty()) { std::fprintf(stderr, "rt_cli: the following required arguments were not provided: --config <CONFIG>\n"); return 2; }
 
@@ -55,8 +71,12 @@ int main(int argc, char** argv) {
     if (rt_config_load(config.c_str(), &cfg)) return die("config");
     RtBuilder* b = nullptr; RtObj world = -1;
     if (rtb_create(&b) || rt_config_build_scene(config.c_str(), scene_seed, b, &world)) return die("scene");
-    RtScene* scene = nullptr;
-    if (rt_scene_create(b, world, device, &scene)) return die("rt_scene_create");
+    const bool multi = !devices.empty();
+    if (!multi) devices.push_back(device);
+    std::vector<RtScene*> scenes(devices.size(), nullptr);
+    for (size_t i = 0; i < devices.size(); ++i)
+        if (rt_scene_create(b, world, devices[i], &scenes[i])) return die("rt_scene_create");
+    RtScene* scene = scenes[0];
     rtb_destroy(b);
 
     RtCamera cam;
@@ -97,7 +117,11 @@ int main(int argc, char** argv) {
     while (done < total_spp) {
         p.spp = checkpoint.empty() ? total_spp : (int)std::min<long long>(pass_spp, total_spp - done);
         p.sample_offset = (int)done;
-        if (rt_render(scene, &cam, &p, accum.data(), nullptr, &st)) return die("rt_render");
+        if (multi) {
+            p.flags = tiles ? RT_FLAG_TILES : 0;
+            if (rt_render_multi(scenes.data(), (int32_t)scenes.size(), &cam, &p, accum.data(), nullptr, &st)) return die("rt_render_multi");
+            total.multi_gpus = st.multi_gpus; total.multi_comm_ranks = st.multi_comm_ranks; total.multi_tiles = st.multi_tiles;
+        } else if (rt_render(scene, &cam, &p, accum.data(), nullptr, &st)) return die("rt_render");
         total.rays += st.rays; total.seconds += st.seconds;
         done += p.spp;
         if (!checkpoint.empty() && rt_accum_save(checkpoint.c_str(), accum.data(), p.width, p.height, done, seed)) return die("checkpoint");
@@ -108,6 +132,10 @@ int main(int argc, char** argv) {
     if (rt_write_image(output.c_str(), rgb.data(), p.width, p.height)) return die("write");
     std::fprintf(stderr, "%s: %dx%d, %d spp, depth %d: %.3f s, %llu ray segments, %.1f Mrays/s -> %s\n", cfg.scene_type, p.width, p.height, p.spp,
                  p.max_depth, st.seconds, (unsigned long long)st.rays, st.seconds > 0 ? st.rays / st.seconds / 1e6 : 0.0, output.c_str());
-    rt_scene_destroy(scene);
+    if (multi)
+        std::fprintf(stderr, "rt_render_multi: %zu handles on %d GPUs, %s sharded, RCCL communicator of %d ranks\n", scenes.size(), st.multi_gpus,
+                     st.multi_tiles ? "pixels" : "samples", st.multi_comm_ranks);
+    for (RtScene* s : scenes) rt_scene_destroy(s);
+    if (multi && rt_multi_shutdown()) return die("rt_multi_shutdown");
     return 0;
 }

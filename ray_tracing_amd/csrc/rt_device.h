@@ -128,13 +128,30 @@ RT_HD v3 rt_unit_vector(float u1, float u2) {
     return mk3(r * c, r * s, z);
 }
 
-// Path id = sample_in_pass * n_pixels + pixel.  The quotient comes from one f64 multiply and is exact after one
-// correction step (ids and pixel counts are below 2^32), which is cheaper than a 32-bit integer division.
+// q = a / n, r = a % n for a, n < 2^32 with inv = 1.0 / n: the quotient comes from one f64 multiply and is exact after one
+// correction step, which is cheaper than a 32-bit integer division.
+RT_HD void rt_divmod(uint32_t a, int32_t n, double inv, uint32_t& q, uint32_t& r) {
+    uint32_t qq = (uint32_t)((double)a * inv);
+    int64_t rr = (int64_t)a - (int64_t)qq * (int64_t)n;
+    if (rr < 0) { qq--; rr += n; } else if (rr >= n) { qq++; rr -= n; }
+    q = qq; r = (uint32_t)rr;
+}
+// Pixel index (row * width + column) of entry k of the pass's pixel set (see RtFrameDev).
+RT_HD uint32_t rt_set_pixel(const RtFrameDev& fr, uint32_t k) {
+    if (!fr.subset) return k;
+    uint32_t row, col;
+    rt_divmod(k, fr.set_w, fr.inv_set_w, row, col);
+    if (fr.band > 0) {   // row `row` of the shard's rows -> row of the rectangle: band (row / band) of this shard is band (row / band) * n_shards + shard
+        uint32_t j = row / (uint32_t)fr.band;
+        row = (j * (uint32_t)fr.n_shards + (uint32_t)fr.shard) * (uint32_t)fr.band + (row - j * (uint32_t)fr.band);
+    }
+    return ((uint32_t)fr.set_y0 + row) * (uint32_t)fr.width + (uint32_t)fr.set_x0 + col;
+}
+// Path id = sample_in_pass * n_set + set index.
 RT_HD void rt_split_path(const RtFrameDev& fr, uint32_t pid, uint32_t& pixel, uint32_t& s_local) {
-    uint32_t q = (uint32_t)((double)pid * fr.inv_n_pixels);
-    int64_t r = (int64_t)pid - (int64_t)q * (int64_t)fr.n_pixels;
-    if (r < 0) { q--; r += fr.n_pixels; } else if (r >= fr.n_pixels) { q++; r -= fr.n_pixels; }
-    s_local = q; pixel = (uint32_t)r;
+    uint32_t k;
+    rt_divmod(pid, fr.n_set, fr.inv_n_set, s_local, k);
+    pixel = rt_set_pixel(fr, k);
 }
 
 // ------------------------------------------------------------------ camera (cameras.rs:82-98)
@@ -406,7 +423,7 @@ RT_HD void rt_node_step4(const Nodes& nodes, RtTrav& tv, float tmin, const RtHit
     {                                                                                                                     \
         float tn = fmaxf(fmaxf(fmaf(rt_ubyte(nx, K), ax, bx), fmaf(rt_ubyte(ny, K), ay, by)), fmaxf(fmaf(rt_ubyte(nz, K), az, bz), tmin));   \
         float tf = fminf(fminf(fmaf(rt_ubyte(fx, K), ax, bx), fmaf(rt_ubyte(fy, K), ay, by)), fminf(fmaf(rt_ubyte(fz, K), az, bz), hit.t));  \
-        KEY = tn <= tf ? (uint32_t)f2i(tn) : 0xFFFFFFFFu;   /* an absent child's inverted box (lo 255, hi 0) never passes */ \
+        KEY = (tn <= tf && CODE != RT_EMPTY_STACK) ? (uint32_t)f2i(tn) : 0xFFFFFFFFu;   /* an absent child: code RT_EMPTY_STACK and an inverted box (lo 255, hi 0) */ \
     }
     RT_WIDE_CHILD(0, c0, k0) RT_WIDE_CHILD(1, c1, k1) RT_WIDE_CHILD(2, c2, k2) RT_WIDE_CHILD(3, c3, k3)
 #undef RT_WIDE_CHILD

@@ -118,8 +118,14 @@ struct RtFrameDev {
     int32_t max_depth;
     uint32_t key0, key1;     // Philox key = render seed
     float inv_wm1, inv_hm1;  // 1/(W-1), 1/(H-1)   main.rs:572-573
-    double inv_n_pixels;     // for path id -> (sample, pixel) without an integer divide
+    double inv_n_set;        // for path id -> (sample, set index) without an integer divide
     float background[3];
+    // The pixels this pass renders ("the set"): n_set of them, numbered row by row.  subset = 0: the whole image (set index =
+    // pixel index).  subset = 1: the rectangle (x0, y0, w) of which only the row bands of one shard are kept -- bands of
+    // `band` rows dealt round-robin to `n_shards` shards, this one being `shard` (band = 0: every row).
+    int32_t n_set, subset;
+    int32_t set_x0, set_y0, set_w, band, n_shards, shard;
+    double inv_set_w;
 };
 
 #define RT_TMIN 0.001f           /* lib.rs:63 */

@@ -45,3 +45,16 @@ def render_sharded(render_fn, height, width, total_spp, device, sample_base=0, g
     if count > 0:
         render_fn(accum, sample_base + first, count)
     return reduce_accumulators(accum, 0, group)
+
+
+def render_tile_sharded(render_fn, height, width, device, group=None):
+    """Pixel sharding, for renders of fewer samples than GPUs (the reference's outer loops run over pixels, src/main.rs:567-568).
+    render_fn(accum_tensor, shard, n_shards) must ADD every sample of pixel shard `shard` of `n_shards` -- the row bands that
+    ray_tracing_amd.shard_tiles / rt_shard_tiles select -- into accum_tensor ([H, W, 3] float32 on `device`) and leave the other
+    pixels alone.  The shards are disjoint, so the reduce(SUM) to rank 0 only adds zeros to each pixel: rank 0's image equals the
+    one-GPU render bit for bit."""
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    accum = torch.zeros((height, width, 3), dtype=torch.float32, device=device)
+    render_fn(accum, rank, world)
+    return reduce_accumulators(accum, 0, group)

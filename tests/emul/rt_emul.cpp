@@ -8,6 +8,7 @@
 #include <thread>
 #include <vector>
 #include "../../include/rt_hip.h"
+#include "../../ray_tracing_amd/csrc/frame.h"
 #include "../../ray_tracing_amd/csrc/rt_device.h"
 #include "../../ray_tracing_amd/csrc/scene_builder.h"
 
@@ -36,12 +37,7 @@ static void make_cam(const RtCamera* cam, RtCameraDev& cd) {
     rt::make_camera(d, cd);
 }
 static void make_frame(const RtRenderParams* p, RtFrameDev& fr) {
-    std::memset(&fr, 0, sizeof(fr));
-    fr.width = p->width; fr.height = p->height; fr.n_pixels = p->width * p->height; fr.max_depth = p->max_depth;
-    fr.key0 = (uint32_t)p->seed; fr.key1 = (uint32_t)(p->seed >> 32);
-    fr.inv_wm1 = (float)(1.0 / (double)(p->width - 1)); fr.inv_hm1 = (float)(1.0 / (double)(p->height - 1));
-    fr.inv_n_pixels = 1.0 / (double)fr.n_pixels;
-    for (int c = 0; c < 3; ++c) fr.background[c] = p->background[c];
+    rt_make_frame(p, fr);
     fr.sample_base = p->sample_offset; fr.spp_chunk = p->spp;
 }
 
@@ -82,7 +78,9 @@ void emul_render(const RtSceneView* sc, const RtCamera* cam, const RtRenderParam
     if (n_threads < 1) n_threads = 1;
     std::vector<uint64_t> rays((size_t)n_threads, 0);
     auto worker = [&](int tid) {
-        for (uint32_t pixel = (uint32_t)tid; pixel < (uint32_t)fr.n_pixels; pixel += (uint32_t)n_threads) {
+        for (uint32_t k = (uint32_t)tid; k < (uint32_t)fr.n_set; k += (uint32_t)n_threads) {   // the pixels of the call's set, as the kernels number them
+            uint32_t pixel, s0;
+            rt_split_path(fr, k, pixel, s0);
             float sum[3] = {0, 0, 0}, sq[3] = {0, 0, 0};
             for (int s = 0; s < p->spp; ++s) {
                 uint32_t sample = (uint32_t)(p->sample_offset + s);

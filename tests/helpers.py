@@ -92,7 +92,7 @@ def emul():
     if _emul is None:
         csrc = os.path.join(ROOT, "ray_tracing_amd", "csrc")
         srcs = [os.path.join(ROOT, "tests", "emul", "rt_emul.cpp")] + [os.path.join(csrc, f) for f in
-                                                                      ("rt_device.h", "rt_types.h", "scene_builder.cpp", "scene_builder.h", "config.cpp")]
+                                                                      ("rt_device.h", "rt_types.h", "frame.h", "scene_builder.cpp", "scene_builder.h", "config.cpp")]
         _build_if_stale(EMUL_SO, srcs,
                         ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-Wno-unknown-pragmas",
                          "-o", EMUL_SO, srcs[0], os.path.join(csrc, "scene_builder.cpp"), os.path.join(csrc, "config.cpp")],

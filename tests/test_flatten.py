@@ -365,5 +365,12 @@ def test_refit_refuses_what_it_cannot_move():
             flat.set_spheres([bad], [[0, 0, 0, 1]])
     with pytest.raises(rt.RtError):
         flat.set_moving_spheres([bound_id + 3], [[0] * 9])           # a sphere is not a moving sphere
-    flat.set_spheres([b.object_count() - 1], [[2, 0, -5, 0.5]])
+    # a call that fails on a later id must not have written the earlier ones
+    last = b.object_count() - 1
+    before = arrays(flat)["spheres"].copy()
+    with pytest.raises(rt.RtError):
+        flat.set_spheres([last, rect_id], [[7, 7, 7, 3], [0, 0, 0, 1]])
+    assert np.array_equal(arrays(flat)["spheres"], before)
+    flat.set_spheres([last], [[2, 0, -5, 0.5]])
+    assert not np.array_equal(arrays(flat)["spheres"], before)
     flat.refit()

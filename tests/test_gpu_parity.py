@@ -16,22 +16,46 @@ ALL = ["orig_img.yml", "rectangle.yml", "cfg.yml", "two_spheres.yml", "random.ym
 
 
 class GpuBackend:
-    def __init__(self, builder, world):
+    """wavefront=True: primary hits come from the kernels a render launches -- camera rays through the ray queue into k_trace as
+    planned for the scene (binary or 4-wide nodes, LDS-resident or not) or into the fused shading kernel's own search -- instead of
+    the plain per-ray loop of the parity hook."""
+
+    def __init__(self, builder, world, wavefront=False):
         self.scene = rt.Scene(builder, world, 0)
+        self.wavefront = wavefront
 
     def trace_primary(self, cam, p, sample, want_normal, want_uv):
-        return self.scene.trace_primary(cam, p, sample, want_normal, want_uv)
+        return self.scene.trace_primary(cam, p, sample, want_normal, want_uv, wavefront=self.wavefront)
 
     def render(self, cam, p, want_sumsq):
         accum, sumsq, st = self.scene.render(cam, p, want_sumsq=want_sumsq)
         return accum, sumsq, int(st.rays)
 
 
+@pytest.mark.parametrize("wavefront", [False, True], ids=["per_ray_hook", "render_kernels"])
 @pytest.mark.parametrize("name", ALL)
-def test_primary_hits_at_config_size(gpu_required, name):
+def test_primary_hits_at_config_size(gpu_required, name, wavefront):
     cfg, cam, b, world, ob = scene_pair(name)
-    agree, rel = check_primary(GpuBackend(b, world), ob, cam, cfg.image_width, cfg.image_height, samples=(0, 9))
+    agree, rel = check_primary(GpuBackend(b, world, wavefront), ob, cam, cfg.image_width, cfg.image_height, samples=(0, 9))
     print("%s %dx%d: ids agree on %.6f, max rel t %.2e" % (name, cfg.image_width, cfg.image_height, agree, rel))
+
+
+@pytest.mark.parametrize("env", [{"RT_TRACE_BVH4": "1"}, {"RT_SHADE_FUSED": "0"}, {"RT_SHADE_FLAT": "0"}, {"RT_TRACE_WIDE_STACK": "1"}, {"RT_TRACE_BLOCK": "256"}],
+                         ids=["wide4_in_lds", "unfused", "fused_tree_walk", "wide_stack", "small_blocks"])
+@pytest.mark.parametrize("name", ["cornell.yml", "final_scene.yml", "showcase.yml"])
+def test_primary_hits_through_every_closest_hit_variant(gpu_required, name, env):
+    """The other forms the closest-hit kernels can take (the 4-wide tree forced onto an LDS-resident scene, k_trace instead of the
+    fused kernel, the fused kernel's tree walk instead of its flat scan, 32-bit stack entries, 256-thread blocks), each held to
+    the oracle directly at the config's size."""
+    cfg, cam, b, world, ob = scene_pair(name)
+    os.environ.update(env)
+    try:
+        backend = GpuBackend(b, world, True)
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+    agree, rel = check_primary(backend, ob, cam, cfg.image_width, cfg.image_height, samples=(3,))
+    print("%s %s: ids agree on %.6f, max rel t %.2e" % (name, env, agree, rel))
 
 
 @pytest.mark.parametrize("name", ALL)
@@ -56,6 +80,8 @@ def test_uv_matches_oracle(gpu_required):
     W, H = 100, 80
     p = rt.render_params(W, H, 1, 50, RENDER_SEED)
     g = scene.trace_primary(cam, p, 0, True, True)
+    gw = scene.trace_primary(cam, p, 0, True, True, wavefront=True)           # the render kernels' hits give the same records
+    assert np.array_equal(gw["id"], g["id"]) and np.array_equal(gw["uv"], g["uv"]) and np.array_equal(gw["front"], g["front"])
     L, oc = oracle(), OracleCamera(cam)
     ray, out = (C.c_double * 7)(), (C.c_double * 10)()
     checked = 0

@@ -27,8 +27,11 @@ def stress_world():
     return b, w, ob
 
 
+@pytest.mark.parametrize("wavefront", [False, True], ids=["per_ray_hook", "render_kernels_wide4"])
 @pytest.mark.parametrize("flags", [0, rt.RT_BVH_LINEAR], ids=["sah_tree", "device_built_linear_tree"])
-def test_one_million_spheres_primary_hits_match_oracle(gpu_required, stress_world, flags):
+def test_one_million_spheres_primary_hits_match_oracle(gpu_required, stress_world, flags, wavefront):
+    """wavefront: the hits come from k_trace over the 4-wide quantised tree (rt_node_step4), the only traversal a render of this
+    scene uses, instead of the per-ray walk of the binary tree."""
     b, w, ob = stress_world
     scene = rt.Scene(b, w, 0, flags)
     info = scene.info()
@@ -37,7 +40,7 @@ def test_one_million_spheres_primary_hits_match_oracle(gpu_required, stress_worl
     W, H = 480, 270
     oc = OracleCamera(cam)
     for sample in (0, 5):
-        g = scene.trace_primary(cam, rt.render_params(W, H, 1, 50, RENDER_SEED), sample)
+        g = scene.trace_primary(cam, rt.render_params(W, H, 1, 50, RENDER_SEED), sample, wavefront=wavefront)
         o = oracle_trace_primary(ob, oc, W, H, sample, RENDER_SEED)
         agree, rel = primary_agreement(g, o)
         assert agree >= ID_AGREEMENT and rel <= T_REL_TOL, (agree, rel)
@@ -147,8 +150,9 @@ def test_queue_overflow_is_reported_not_rendered(gpu_required):
 
 
 def test_render_multi_on_one_gpu_equals_render(gpu_required):
-    """rt_render_multi with one scene: host thread, private accumulator, the RCCL reduce (a one-rank communicator) and the
-    host add must give rt_render's image bit for bit; the same handle twice is refused."""
+    """rt_render_multi with one scene: host thread, private accumulator and the host add must give rt_render's image bit for bit,
+    without RCCL (one GPU has nothing to reduce) and, forced through it, with a one-rank communicator; rt_multi_shutdown destroys
+    the communicator and the next call makes a new one; the same handle twice is refused."""
     cfg, cam, b, world, _ = scene_pair("final_scene.yml")
     scene = rt.Scene(b, world, 0)
     p = rt.render_params(160, 120, 6, cfg.max_depth, RENDER_SEED, sample_offset=3)
@@ -156,6 +160,16 @@ def test_render_multi_on_one_gpu_equals_render(gpu_required):
     got, got_sq, st2 = rt.render_multi([scene], cam, p, want_sumsq=True)
     assert st2.rays == st.rays and st2.paths == st.paths
     assert np.array_equal(got, want) and np.array_equal(got_sq, want_sq)
+    assert (st2.multi_gpus, st2.multi_comm_ranks, st2.multi_tiles) == (1, 0, 0)
+    os.environ["RT_MULTI_FORCE_RCCL"] = "1"
+    try:
+        for _ in range(2):                                            # the second round after a shutdown: a fresh communicator
+            got, got_sq, st3 = rt.render_multi([scene], cam, p, want_sumsq=True)
+            assert np.array_equal(got, want) and np.array_equal(got_sq, want_sq) and (st3.multi_gpus, st3.multi_comm_ranks) == (1, 1)
+            rt.multi_shutdown()
+    finally:
+        os.environ.pop("RT_MULTI_FORCE_RCCL", None)
+    rt.multi_shutdown()                                               # nothing left to destroy: still fine
     again, _, _ = rt.render_multi([scene], cam, p, accum=got.copy())  # adds into the caller's buffer; the communicator is reused
     assert np.array_equal(again, 2 * want)
     with pytest.raises(rt.RtError) as e:
@@ -178,8 +192,59 @@ def test_render_multi_with_three_handles_on_one_gpu(gpu_required):
     assert np.allclose(got, want, rtol=2e-6, atol=1e-6) and np.allclose(got_sq, want_sq, rtol=2e-6, atol=1e-6)
     parts = [scenes[0].render(cam, rt.render_params(120, 96, c, cfg.max_depth, RENDER_SEED, sample_offset=11 + f))[0] for f, c in ((0, 3), (3, 2), (5, 2))]
     assert np.array_equal(got, (parts[0] + parts[1]) + parts[2])     # the shards, added in handle order
+    assert (st2.multi_gpus, st2.multi_tiles) == (1, 0)
+    # fewer samples than handles: the pixels are sharded instead (every handle traces both samples of its row bands), nothing is
+    # summed across handles, and the image is the one-call render bit for bit; the same when pixel sharding is asked for
+    for spp, flags in ((2, 0), (7, rt.RT_FLAG_TILES)):
+        q = rt.render_params(120, 96, spp, cfg.max_depth, RENDER_SEED, sample_offset=11, flags=flags)
+        want, want_sq, st = scenes[0].render(cam, rt.render_params(120, 96, spp, cfg.max_depth, RENDER_SEED, sample_offset=11), want_sumsq=True)
+        got, got_sq, st2 = rt.render_multi(scenes, cam, q, want_sumsq=True)
+        assert st2.multi_tiles == 1 and st2.multi_comm_ranks == 0
+        assert st2.rays == st.rays and st2.paths == st.paths and np.array_equal(got, want) and np.array_equal(got_sq, want_sq)
+    # a shard without samples (its accumulator holds only the memset): 2 samples over 3 handles, forced to shard by samples
+    # cannot be asked for, so the zero-sample case is spp = 0
+    got, _, st2 = rt.render_multi(scenes, cam, rt.render_params(120, 96, 0, cfg.max_depth, RENDER_SEED))
+    assert st2.rays == 0 and np.all(got == 0)
     for s in scenes:
         s.close()
+
+
+def test_pixel_shards_tile_the_image_bit_for_bit(gpu_required):
+    """RtRenderParams.tile / .stripe: a rectangle, the row bands of rt_shard_tiles, and both together render exactly the pixels
+    they name with the values a whole-image render gives them, and leave the others alone."""
+    cfg, cam, b, world, _ = scene_pair("final_scene.yml")
+    scene = rt.Scene(b, world, 0)
+    W, H, spp = 150, 101, 3                                            # 101 rows: 13 bands of 8, the last one short
+    base = rt.render_params(W, H, spp, cfg.max_depth, RENDER_SEED, sample_offset=4)
+    whole, whole_sq, st = scene.render(cam, base, want_sumsq=True)
+    for n in (3, 5, 16):                                               # 16 > 13 bands: three shards are empty
+        total, rays, pixels = np.zeros_like(whole), 0, 0
+        for i in range(n):
+            q, count = rt.shard_tiles(base, i, n)
+            part, _, sp = scene.render(cam, q)
+            assert sp.paths == count * spp and np.count_nonzero(part.sum(axis=2)) <= count
+            assert not np.any((total != 0) & (part != 0))             # disjoint
+            total += part; rays += int(sp.rays); pixels += count
+        assert pixels == W * H and rays == st.rays and np.array_equal(total, whole)
+    x0, y0, w, h = 17, 9, 64, 50
+    rect, rect_sq, sr = scene.render(cam, rt.render_params(W, H, spp, cfg.max_depth, RENDER_SEED, sample_offset=4, tile=(x0, y0, w, h)), want_sumsq=True)
+    mask = np.zeros((H, W, 1), bool); mask[y0:y0 + h, x0:x0 + w] = True
+    assert sr.paths == w * h * spp and np.array_equal(rect, np.where(mask, whole, 0)) and np.array_equal(rect_sq, np.where(mask, whole_sq, 0))
+    both = np.zeros_like(whole)
+    for i in range(2):                                                 # bands of 5 rows of the rectangle, dealt to two shards
+        scene.render(cam, rt.render_params(W, H, spp, cfg.max_depth, RENDER_SEED, sample_offset=4, tile=(x0, y0, w, h), stripe=(5, 2, i)), accum=both)
+    assert np.array_equal(both, rect)
+    # the no-allocation entry point takes the same selection (its limit is on the pixels rendered)
+    import torch
+    acc = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    scene.render_device_noalloc(cam, rt.render_params(W, H, spp, cfg.max_depth, RENDER_SEED, sample_offset=4, tile=(x0, y0, w, h)), acc.data_ptr(), None, None)
+    torch.cuda.synchronize()
+    assert np.array_equal(acc.cpu().numpy(), rect)
+    for bad in (dict(tile=(0, 0, W + 1, 4)), dict(tile=(-1, 0, 4, 4)), dict(tile=(0, 0, 0, 4)), dict(stripe=(0, 2, 1)), dict(stripe=(8, 2, 2)), dict(stripe=(8, 0, 0))):
+        with pytest.raises(rt.RtError) as e:
+            scene.render(cam, rt.render_params(W, H, 1, 5, 1, **bad))
+        assert e.value.code == -1
+    scene.close()
 
 
 def test_render_sharded_with_the_hip_renderer(gpu_required):
@@ -217,6 +282,7 @@ def test_refit_on_the_gpu_gives_the_hits_of_a_rebuild(gpu_required, flags):
     cam = rt.make_camera((0, 6, 12), (0, 2, -18), (0, 1, 0), 45.0, 1.5, 0.05, 20.0)
     W, H = 300, 200
     p = rt.render_params(W, H, 4, 50, RENDER_SEED, background=SKY)
+    oracle_hits = None
     for wide in ("0", "1"):
         os.environ["RT_TRACE_BVH4"] = wide
         try:
@@ -234,6 +300,17 @@ def test_refit_on_the_gpu_gives_the_hits_of_a_rebuild(gpu_required, flags):
             fresh = rt.Scene(b2, w2, 0, flags)
             got, want = scene.trace_primary(cam, p, 0), fresh.trace_primary(cam, p, 0)
             assert np.array_equal(got["id"], want["id"]) and np.array_equal(got["t"], want["t"])
+            # ... and those of the oracle built at the moved positions, through the kernels a render runs on the refitted trees
+            via = scene.trace_primary(cam, p, 0, wavefront=True)
+            assert np.array_equal(via["id"], got["id"]) and np.array_equal(via["t"], got["t"])
+            if oracle_hits is None:
+                ob = OracleBuilder()
+                ow, _, _, _ = moving_scene(ob, pos1, rad1, cl1, ms1)
+                ob.set_world(ow)
+                oracle_hits = oracle_trace_primary(ob, OracleCamera(cam), W, H, 0, RENDER_SEED)
+                assert (oracle_hits["id"] >= 0).mean() > 0.5
+            agree, rel = primary_agreement(via, oracle_hits)
+            assert agree >= ID_AGREEMENT and rel <= T_REL_TOL, (wide, agree, rel)
             img, _, st = scene.render(cam, p)
             ref, _, st2 = fresh.render(cam, p)
             assert st.rays == st2.rays and np.array_equal(img, ref) and not np.array_equal(img, before)

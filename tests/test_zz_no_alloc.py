@@ -65,3 +65,36 @@ def test_noalloc_refuses_what_does_not_fit(gpu_required):
     st = scene.render_device_noalloc(cam, rt.render_params(512, 512, 1, 126, 1), acc.data_ptr(), None, None)   # exactly at both limits
     assert st.rays >= 512 * 512
     scene.close()
+
+
+def test_noalloc_allocates_nothing_and_runs_under_graph_capture(gpu_required):
+    """The property itself: the GPU's free memory is the same before and after ten calls, and a call is legal between
+    hipStreamBeginCapture and hipStreamEndCapture (where an allocation or a synchronisation would fail the capture); replays
+    of the captured graph give rt_render_device's image."""
+    import torch
+    cfg, cam, b, world, _ = scene_pair("final_scene.yml")
+    scene = rt.Scene(b, world, 0)
+    W, H, spp = 97, 61, 7
+    p = rt.render_params(W, H, spp, cfg.max_depth, RENDER_SEED, sample_offset=2)
+    want = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda:0")
+    acc = torch.zeros_like(want)
+    stream = torch.cuda.current_stream().cuda_stream
+    scene.render_device(cam, rt.render_params(W, H, spp, cfg.max_depth, RENDER_SEED, sample_offset=2, paths_per_pass=MAX_PATHS), want.data_ptr(), None, stream)
+    scene.render_device_noalloc(cam, p, acc.data_ptr(), None, stream)            # first call: code objects are loaded by now
+    torch.cuda.synchronize()
+    assert np.array_equal(acc.cpu().numpy(), want.cpu().numpy())
+    free_before = torch.cuda.mem_get_info(0)[0]
+    for k in range(10):
+        scene.render_device_noalloc(cam, p, acc.data_ptr(), None, stream, want_stats=(k % 2 == 0))
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(0)[0] == free_before
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        scene.render_device_noalloc(cam, p, acc.data_ptr(), None, torch.cuda.current_stream().cuda_stream, want_stats=False)
+    for _ in range(2):
+        acc.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(acc.cpu().numpy(), want.cpu().numpy())
+    del graph
+    scene.close()
