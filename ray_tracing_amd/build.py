@@ -48,5 +48,14 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_host_asan():
+    """AddressSanitizer + UndefinedBehaviorSanitizer build of the host sources (no HIP file) and the oracle, linked into the test
+    driver tests/asan/host_asan_driver (see oracle/Makefile, target `asan`)."""
+    subprocess.run(["make", "asan"], check=True, cwd=os.path.join(HERE, "..", "oracle"))
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True)
+    if "--host-asan" in sys.argv:
+        build_host_asan()
+    else:
+        build(force="--force" in sys.argv, verbose=True)

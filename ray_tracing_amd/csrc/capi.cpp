@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include "capi_internal.h"
+#include "frame.h"
 
 thread_local std::string g_rt_error;
 int rt_set_error(int code, const std::string& msg) { g_rt_error = msg; return code; }
@@ -16,6 +17,16 @@ static rt::Vec3 v3d(const double* p) { return rt::vec3(p[0], p[1], p[2]); }
 static int handle(RtBuilder* b, int h) { if (h < 0) g_rt_error = b->b.error; return h; }
 #define NEED(b) do { if (!(b)) return rt_set_error(RT_ERR_INVALID, "null builder"); } while (0)
 
+
+// What rt_scene_info / rt_flat_info report about a flattened scene (the device fields are filled by the caller).
+void rt_fill_info(const rt::FlatScene& f, RtSceneInfo* o) {
+    RtSceneView v = f.view();
+    o->n_nodes = v.n_nodes; o->n_spheres = v.n_spheres; o->n_moving_spheres = v.n_mspheres; o->n_rects = v.n_rects; o->n_boxes = v.n_boxes;
+    o->n_instances = v.n_instances; o->n_media = v.n_media; o->n_materials = v.n_materials; o->n_textures = v.n_textures; o->n_perlin = v.n_perlin;
+    o->tlas_depth = f.tlas_depth; o->blas_depth = f.blas_depth; o->max_stack = f.max_stack; o->n_objects = f.n_ids; o->device = -1;
+    for (int i = 0; i < 6; ++i) o->world_box[i] = f.world_box[i];
+    o->device_bytes = 0; o->bvh_build_seconds = 0.0; o->bvh_refit_seconds = 0.0;
+}
 
 extern "C" {
 
@@ -345,6 +356,30 @@ int rt_flat_refit(RtFlat* f) {
 
 // ---- accumulator checkpoints: header {magic, width, height, spp_done, seed} then width * height * 3 floats
 static const uint64_t kAccumMagic = 0x314D554343415452ull;  // "RTACCUM1"
+int rt_flat_info(const RtFlat* f, RtSceneInfo* out) {
+    if (!f || !out) return rt_set_error(RT_ERR_INVALID, "null argument");
+    rt_fill_info(f->flat, out);
+    return RT_OK;
+}
+
+
+// ---- sharding arithmetic of the multi-GPU paths (pure host code)
+int rt_shard_samples(int32_t total_spp, int32_t n_shards, int32_t shard, int32_t* first, int32_t* count) {
+    if (!first || !count || total_spp < 0 || n_shards < 1 || shard < 0 || shard >= n_shards) return rt_set_error(RT_ERR_INVALID, "rt_shard_samples: bad argument");
+    const int32_t base = total_spp / n_shards, extra = total_spp % n_shards;
+    *count = base + (shard < extra ? 1 : 0);
+    *first = shard * base + std::min(shard, extra);
+    return RT_OK;
+}
+
+int rt_shard_tiles(RtRenderParams* p, int32_t n_shards, int32_t shard, int64_t* n_pixels) {
+    if (!p || p->width < 1 || p->height < 1 || n_shards < 1 || shard < 0 || shard >= n_shards) return rt_set_error(RT_ERR_INVALID, "rt_shard_tiles: bad argument");
+    std::memset(p->tile, 0, sizeof(p->tile));
+    p->stripe[0] = RT_TILE_ROWS; p->stripe[1] = n_shards; p->stripe[2] = shard;
+    if (n_pixels) *n_pixels = rt_stripe_rows(p->height, RT_TILE_ROWS, n_shards, shard) * (int64_t)p->width;
+    return RT_OK;
+}
+
 int rt_accum_save(const char* path, const float* accum_rgb, int32_t w, int32_t h, int64_t spp_done, uint64_t seed) {
     if (!path || !accum_rgb || w <= 0 || h <= 0 || spp_done < 0) return rt_set_error(RT_ERR_INVALID, "bad argument");
     std::string tmp = std::string(path) + ".tmp";              // written aside and renamed: a crash never leaves half a file

@@ -11,6 +11,8 @@ struct RtFlat { rt::FlatScene flat; RtSceneView view; std::vector<int32_t> of_id
 extern thread_local std::string g_rt_error;
 int rt_set_error(int code, const std::string& msg);
 
+void rt_fill_info(const rt::FlatScene& f, RtSceneInfo* out);   // capi.cpp
+
 // Status code of a flattener message.
 inline int rt_status_of(const std::string& msg) {
     if (msg.find("No bounding box") != std::string::npos) return RT_ERR_NO_BBOX;

@@ -1231,26 +1231,12 @@ void rt_scene_destroy(RtScene* s) {
     if (last) (void)rt_release_workspace(device);
 }
 
-static void fill_info(const rt::FlatScene& f, RtSceneInfo* o) {
-    RtSceneView v = f.view();
-    o->n_nodes = v.n_nodes; o->n_spheres = v.n_spheres; o->n_moving_spheres = v.n_mspheres; o->n_rects = v.n_rects; o->n_boxes = v.n_boxes;
-    o->n_instances = v.n_instances; o->n_media = v.n_media; o->n_materials = v.n_materials; o->n_textures = v.n_textures; o->n_perlin = v.n_perlin;
-    o->tlas_depth = f.tlas_depth; o->blas_depth = f.blas_depth; o->max_stack = f.max_stack; o->n_objects = f.n_ids; o->device = -1;
-    for (int i = 0; i < 6; ++i) o->world_box[i] = f.world_box[i];
-    o->device_bytes = 0; o->bvh_build_seconds = 0.0; o->bvh_refit_seconds = 0.0;
-}
 int rt_scene_info(const RtScene* s, RtSceneInfo* out) {
     if (!s || !out) return rt_set_error(RT_ERR_INVALID, "null argument");
-    fill_info(s->flat, out); out->device = s->device; out->device_bytes = s->device_bytes; out->bvh_build_seconds = s->bvh_build_seconds;
+    rt_fill_info(s->flat, out); out->device = s->device; out->device_bytes = s->device_bytes; out->bvh_build_seconds = s->bvh_build_seconds;
     out->bvh_refit_seconds = s->refit_seconds;
     return RT_OK;
 }
-int rt_flat_info(const RtFlat* f, RtSceneInfo* out) {
-    if (!f || !out) return rt_set_error(RT_ERR_INVALID, "null argument");
-    fill_info(f->flat, out);
-    return RT_OK;
-}
-
 }  // extern "C"
 
 // The passes of one render call on workspace `ws`: samples [sample_offset, sample_offset + spp) of every pixel, `chunk_max`
@@ -1508,14 +1494,6 @@ int rt_scene_refit(RtScene* s) {
     return RT_OK;
 }
 
-int rt_shard_samples(int32_t total_spp, int32_t n_shards, int32_t shard, int32_t* first, int32_t* count) {
-    if (!first || !count || total_spp < 0 || n_shards < 1 || shard < 0 || shard >= n_shards) return rt_set_error(RT_ERR_INVALID, "rt_shard_samples: bad argument");
-    const int32_t base = total_spp / n_shards, extra = total_spp % n_shards;
-    *count = base + (shard < extra ? 1 : 0);
-    *first = shard * base + std::min(shard, extra);
-    return RT_OK;
-}
-
 }  // extern "C"
 
 // ---- RCCL, loaded on first use: a caller that renders on one GPU never needs the library.  When PyTorch is in the process its
@@ -1607,14 +1585,6 @@ int rt_multi_shutdown(void) {
     }
     g_rccl_comms.clear();
     return rc;
-}
-
-int rt_shard_tiles(RtRenderParams* p, int32_t n_shards, int32_t shard, int64_t* n_pixels) {
-    if (!p || p->width < 1 || p->height < 1 || n_shards < 1 || shard < 0 || shard >= n_shards) return rt_set_error(RT_ERR_INVALID, "rt_shard_tiles: bad argument");
-    std::memset(p->tile, 0, sizeof(p->tile));
-    p->stripe[0] = RT_TILE_ROWS; p->stripe[1] = n_shards; p->stripe[2] = shard;
-    if (n_pixels) *n_pixels = rt_stripe_rows(p->height, RT_TILE_ROWS, n_shards, shard) * (int64_t)p->width;
-    return RT_OK;
 }
 
 int rt_render_multi(RtScene* const* scenes, int32_t n_scenes, const RtCamera* cam, const RtRenderParams* p, float* accum, float* accum_sq, RtStats* stats) {
