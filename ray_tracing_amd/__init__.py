@@ -133,9 +133,10 @@ def lib():
     """Loads librt_hip.so (built in-tree by ray_tracing_amd/build.py).  Fails loudly if it is absent."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("RT_HIP_LIB") or LIB_PATH      # RT_HIP_LIB: another build of the same library (A/B measurements)
+        if not os.path.exists(path):
             raise ImportError("%s is missing: run `python -m ray_tracing_amd.build` (needs hipcc); "
-                              "there is no CPU fallback for the render path" % LIB_PATH)
+                              "there is no CPU fallback for the render path" % path)
         # PyTorch-ROCm bundles its own HIP runtime (same soname as the system one).  Two runtimes in one process
         # leave the second user without a GPU, so when torch is installed it is imported first and the library
         # binds to the runtime torch brought in; device pointers are then shared between the two.
@@ -145,9 +146,13 @@ def lib():
                 import torch  # noqa: F401
             except ImportError:
                 pass
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(path)
         for name, (res, args) in API.items():
-            fn = getattr(L, name)
+            fn = getattr(L, name, None)
+            if fn is None:
+                if path == LIB_PATH:
+                    raise ImportError("%s does not export %s: rebuild it (python -m ray_tracing_amd.build)" % (path, name))
+                continue                                      # an older build given through RT_HIP_LIB may lack newer entry points
             fn.restype, fn.argtypes = res, args
         _lib = L
     return _lib

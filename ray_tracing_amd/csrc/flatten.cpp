@@ -97,6 +97,7 @@ public:
             for (int a = 0; a < 3; ++a) { out.world_box[a] = wb.mn[a]; out.world_box[3 + a] = wb.mx[a]; }
             out.root = -1; out.tlas_depth = 0;
             out.max_stack = out.instances.empty() ? 0 : 1 + max_blas;   // the top level's depth is added when it exists
+            emit_medium_locals(top);
             relabel_breadth_first();
             return err.empty();
         }
@@ -111,6 +112,7 @@ public:
         }
         out.max_stack = out.tlas_depth + (out.instances.empty() ? 0 : 1 + max_blas);
         if (out.max_stack > RT_STACK_DEPTH) return fail("flatten: BVH deeper than the traversal stack");
+        emit_medium_locals(top);
         relabel_breadth_first();
         if (!err.empty()) return false;
         return true;
@@ -123,6 +125,7 @@ private:
     std::vector<std::vector<PrimRef>> chain_prims;
     std::vector<MediumRef> media;
     std::vector<int> chain_instance;  // chain -> instance index (for media boundaries), -1 if none yet
+    std::vector<int> index_of_obj;    // object -> index of its record in its kind's array (emit_prim)
 
     bool fail(const std::string& m) { err = m; return false; }
 
@@ -216,6 +219,12 @@ private:
 
     // ---- emitters
     int emit_prim(int oi) {  // returns the index inside the primitive's kind array
+        const int idx = emit_prim_record(oi);
+        if (index_of_obj.size() < b.objects.size()) index_of_obj.resize(b.objects.size(), -1);
+        index_of_obj[(size_t)oi] = idx;
+        return idx;
+    }
+    int emit_prim_record(int oi) {
         const ObjNode& o = b.objects[oi];
         rt_i2 meta; meta.x = o.mat; meta.y = o.id;
         if (o.type == OBJ_SPHERE) {
@@ -236,6 +245,66 @@ private:
         out.rects.push_back(f4((float)o.p[0], (float)o.p[1], (float)o.p[2], (float)o.p[3]));
         out.rects.push_back(f4((float)o.p[4], i2f(o.rect_type), 0, 0));
         out.rect_meta.push_back(meta); return (int)out.rect_meta.size() - 1;
+    }
+    // The surfaces a ray can meet while it is still inside a medium (src/mediums.rs:39-87 scatters rays from points inside the
+    // boundary; the reference then searches the whole world again, src/lib.rs:63).  For a medium whose boundary is one sphere or
+    // one box in world space, every surface point inside the boundary belongs to a primitive that meets the boundary's solid:
+    // when those are at most three world-space primitives, the medium record lists them (as one-primitive leaf codes in m4.z,
+    // m4.w, m5.w; m5.z = count | mask << 8, bit k of the mask: entry k lies wholly inside the boundary).  A ray that starts
+    // inside the boundary and hits a flagged primitive has found its closest surface hit -- anything nearer would lie inside
+    // the boundary too and be in the list -- so the shading kernel can settle that ray's closest-hit search itself.  An instance
+    // near the boundary, or more than three candidates, leave the list empty and every ray goes through the tree.
+    void emit_medium_locals(const std::vector<Item>& top) {
+        if (index_of_obj.size() < b.objects.size()) index_of_obj.resize(b.objects.size(), -1);
+        for (size_t mi = 0; mi < media.size(); ++mi) {
+            rt_f4* rec = &out.media[mi * RT_MEDIUM_F4];
+            int32_t fast, has_inst;
+            std::memcpy(&fast, &rec[5].x, 4); std::memcpy(&has_inst, &rec[5].y, 4);
+            if (fast == 0 || has_inst) continue;
+            const ObjNode& bo = b.objects[media[mi].boundary[0].obj];
+            const Box3 bb = prim_box(bo);
+            const double size = std::fabs(bb.mx[0] - bb.mn[0]) + std::fabs(bb.mx[1] - bb.mn[1]) + std::fabs(bb.mx[2] - bb.mn[2]);
+            const double pad = 1e-3 * (1.0 + size);
+            // does the item's box come within `pad` of the boundary's solid?  (sphere boundary: distance from its centre to the box)
+            auto meets = [&](const Box3& x) {
+                if (fast == 1) {
+                    double d2 = 0.0;
+                    for (int a = 0; a < 3; ++a) { const double c = bo.p[a], d = c < x.mn[a] ? x.mn[a] - c : (c > x.mx[a] ? c - x.mx[a] : 0.0); d2 += d * d; }
+                    return std::sqrt(d2) <= std::fabs(bo.p[3]) + pad;
+                }
+                for (int a = 0; a < 3; ++a) if (!(x.mn[a] <= bb.mx[a] + pad && x.mx[a] >= bb.mn[a] - pad)) return false;
+                return true;
+            };
+            int codes[3] = {0, 0, 0}, n = 0, mask = 0; bool ok = true;
+            for (const Item& it : top) {
+                if (!meets(it.box)) continue;
+                if (it.cls == kInstanceClass || n == 3 || index_of_obj[(size_t)it.ref] < 0) { ok = false; break; }
+                bool inside = true;    // every corner of the primitive's box within the boundary (a sphere against a sphere boundary: exactly)
+                const ObjNode& po = b.objects[(size_t)it.ref];
+                if (fast == 1) {
+                    const double r = std::fabs(bo.p[3]) * (1.0 + 1e-6);
+                    if (po.type == OBJ_SPHERE) {
+                        const double dx = po.p[0] - bo.p[0], dy = po.p[1] - bo.p[1], dz = po.p[2] - bo.p[2];
+                        inside = std::sqrt(dx * dx + dy * dy + dz * dz) + std::fabs(po.p[3]) <= r;
+                    } else
+                        for (int c = 0; c < 8 && inside; ++c) {
+                            const double dx = ((c & 1) ? it.box.mx[0] : it.box.mn[0]) - bo.p[0], dy = ((c & 2) ? it.box.mx[1] : it.box.mn[1]) - bo.p[1],
+                                         dz = ((c & 4) ? it.box.mx[2] : it.box.mn[2]) - bo.p[2];
+                            inside = std::sqrt(dx * dx + dy * dy + dz * dz) <= r;
+                        }
+                } else
+                    for (int a = 0; a < 3; ++a) {
+                        const double tol = 1e-6 * (1.0 + std::fabs(bb.mn[a]) + std::fabs(bb.mx[a]));
+                        inside = inside && it.box.mn[a] >= bb.mn[a] - tol && it.box.mx[a] <= bb.mx[a] + tol;
+                    }
+                codes[n] = rt_leaf_prims(it.cls, index_of_obj[(size_t)it.ref], 1);
+                if (inside) mask |= 1 << n;
+                ++n;
+            }
+            if (!ok || n == 0 || mask == 0) continue;
+            rec[4].z = i2f(codes[0]); rec[4].w = i2f(codes[1]); rec[5].w = i2f(codes[2]);
+            rec[5].z = i2f(n | (mask << 8));
+        }
     }
     int emit_instance(int chain, int root) {
         // Collapse the chain into one affine map: object point = R * world + c.

@@ -16,6 +16,11 @@
 // and grid-stride step: 256 for k_shade, 1024 for k_shade_lds).
 // Queue sizes live in device memory (counts[b][s] = rays of region s entering bounce b), so a pass runs
 // without a host round trip; the counts double as the ray-segment statistics.
+// A region is filled from both ends.  Rays that need the closest-hit kernel are appended from slot 0 upwards (count: counts[b][s]);
+// rays whose closest surface hit the shading kernel has settled itself (shade_ray: steps of a walk inside a medium whose boundary
+// encloses a known handful of surfaces) are appended from slot cap - 1 downwards (count: back[b][s]) together with their hit
+// record.  k_trace walks the front part only, so it never meets a ray it has nothing to do for; the shading kernels walk both.
+// The capacity bound above is on the sum of the two parts.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
@@ -111,7 +116,8 @@ struct RtTracePlan {
     int32_t first_lds;                                                    // 0 for a breadth-first array; a device-built tree keeps copies of its top at the end
     int32_t off_spheres, off_mspheres, off_rects, off_boxes, off_instances;
     int32_t off_stack;                                                    // first record of the stack
-    int32_t stack_cap;                                                    // stack entries per lane
+    int32_t stack_cap;                                                    // stack entries per lane held in LDS
+    int32_t stack_total;                                                  // entries a lane may need in all; those beyond stack_cap live in global memory (spill)
     int32_t wide_stack;                                                   // 1: 32-bit entries, 0: 16-bit entries (TraceStack)
     int32_t resident;                                                     // 1: all nodes and all primitive arrays are in LDS
     int32_t refill_lanes;                                                 // idle lanes of a wave that trigger a refill
@@ -160,41 +166,53 @@ template <bool RESIDENT> struct TracePrims {   // primitive records: every array
 // parent (node << 1 | which); the child code is re-read from the parent's record, which must be in LDS.  Half the LDS of
 // the 32-bit form, which is what lets a small scene's primitives sit in LDS beside its nodes.
 typedef __attribute__((address_space(3))) unsigned short lds_u16;
-template <bool WIDE> struct TraceStack;
-template <> struct TraceStack<true> {
-    lds_int* base; int depth, stride;
-    __device__ __forceinline__ void put(int i, int, int, int code) { base[i * stride] = code; }
-    __device__ __forceinline__ void put_sentinel(int i) { base[i * stride] = RT_SENTINEL; }
-    __device__ __forceinline__ int take(int i) const { return base[i * stride]; }
-    __device__ __forceinline__ int cap() const { return depth; }
+// Entries [0, depth) of a lane's stack are in LDS; deeper ones -- which few rays ever reach: the worst case follows from the
+// tree's depth, the depth in use is a handful (0.07 % of final_scene.yml's node steps have more than 8 entries pending, 0.3 % of
+// the 1M-sphere scene's more than 10) -- go to a global spill area, [entry][thread of the grid].  The LDS this frees holds scene data.
+// SPILL = false: the whole stack is in LDS and the accessors have no global-memory path (a branch and a VMEM access in the node loop
+// cost k_trace 11 % on final_scene.yml even when never taken).
+template <bool WIDE, bool SPILL> struct TraceStack;
+template <bool SPILL> struct TraceStack<true, SPILL> {
+    lds_int* base; int depth, stride, total; int* spill; size_t spill_stride;
+    __device__ __forceinline__ void put(int i, int, int, int code) { if (!SPILL || i < depth) base[i * stride] = code; else spill[(size_t)(i - depth) * spill_stride] = code; }
+    __device__ __forceinline__ void put_sentinel(int i) { put(i, 0, 0, RT_SENTINEL); }
+    __device__ __forceinline__ int take(int i) const { return (!SPILL || i < depth) ? base[i * stride] : spill[(size_t)(i - depth) * spill_stride]; }
+    __device__ __forceinline__ int cap() const { return total; }
 };
-template <> struct TraceStack<false> {
-    lds_u16* base; lds_int* node_words; int depth, stride;
-    __device__ __forceinline__ void put(int i, int node, int which, int) { base[i * stride] = (unsigned short)((node << 1) | which); }
-    __device__ __forceinline__ void put_sentinel(int i) { base[i * stride] = (unsigned short)0xFFFFu; }
+template <bool SPILL> struct TraceStack<false, SPILL> {
+    lds_u16* base; lds_int* node_words; int depth, stride, total; unsigned short* spill; size_t spill_stride;
+    __device__ __forceinline__ void put_raw(int i, unsigned short e) { if (!SPILL || i < depth) base[i * stride] = e; else spill[(size_t)(i - depth) * spill_stride] = e; }
+    __device__ __forceinline__ void put(int i, int node, int which, int) { put_raw(i, (unsigned short)((node << 1) | which)); }
+    __device__ __forceinline__ void put_sentinel(int i) { put_raw(i, (unsigned short)0xFFFFu); }
     __device__ __forceinline__ int take(int i) const {
-        uint32_t e = base[i * stride];
+        uint32_t e = (!SPILL || i < depth) ? (uint32_t)base[i * stride] : (uint32_t)spill[(size_t)(i - depth) * spill_stride];
         return e == 0xFFFFu ? RT_SENTINEL : node_words[(e >> 1) * 16u + 12u + (e & 1u)];
     }
-    __device__ __forceinline__ int cap() const { return depth; }
+    __device__ __forceinline__ int cap() const { return total; }
 };
-template <bool WIDE> __device__ __forceinline__ TraceStack<WIDE> make_stack(unsigned char* smem, int off_stack, int depth, int threads);
-template <> __device__ __forceinline__ TraceStack<true> make_stack<true>(unsigned char* smem, int off_stack, int depth, int threads) {
-    TraceStack<true> s; s.base = (lds_int*)(smem + (size_t)off_stack * 16) + threadIdx.x; s.depth = depth; s.stride = threads; return s;
-}
-template <> __device__ __forceinline__ TraceStack<false> make_stack<false>(unsigned char* smem, int off_stack, int depth, int threads) {
-    TraceStack<false> s; s.base = (lds_u16*)(smem + (size_t)off_stack * 16) + threadIdx.x; s.node_words = (lds_int*)smem;
-    s.depth = depth; s.stride = threads; return s;
-}
+// spill: the scene's spill area (null when every entry is in LDS); `gthread` = this thread's index in the grid
+template <bool WIDE, bool SPILL> struct MakeStack;
+template <bool SPILL> struct MakeStack<true, SPILL> {
+    static __device__ __forceinline__ TraceStack<true, SPILL> make(unsigned char* smem, const RtTracePlan& pl, int threads, void* spill, size_t gthread, size_t gthreads) {
+        TraceStack<true, SPILL> s; s.base = (lds_int*)(smem + (size_t)pl.off_stack * 16) + threadIdx.x; s.depth = pl.stack_cap; s.total = pl.stack_total; s.stride = threads;
+        s.spill = (int*)spill + gthread; s.spill_stride = gthreads; return s;
+    }
+};
+template <bool SPILL> struct MakeStack<false, SPILL> {
+    static __device__ __forceinline__ TraceStack<false, SPILL> make(unsigned char* smem, const RtTracePlan& pl, int threads, void* spill, size_t gthread, size_t gthreads) {
+        TraceStack<false, SPILL> s; s.base = (lds_u16*)(smem + (size_t)pl.off_stack * 16) + threadIdx.x; s.node_words = (lds_int*)smem;
+        s.depth = pl.stack_cap; s.total = pl.stack_total; s.stride = threads; s.spill = (unsigned short*)spill + gthread; s.spill_stride = gthreads; return s;
+    }
+};
 
 // Persistent grid, one ray per lane.  The scene (node array and, when they fit, the primitive arrays) is copied into
 // the block's LDS once; traversal then touches global memory only for the ray records in and the hit records out.
 // A lane that has finished its ray waits until `refill_lanes` lanes of its wave are idle; the idle lanes then take the
 // next rays of the region through one wave-aggregated atomic on the region's cursor (ballot + mbcnt ranks).  A wave
 // therefore never drains to a few long rays, which is what a ray-per-thread launch costs on 64-wide waves.
-template <bool STATS, int TB, bool WIDE, bool RESIDENT, bool WIDE4>
+template <bool STATS, int TB, bool WIDE, bool RESIDENT, bool WIDE4, bool SPILL>
 __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, uint32_t cap, const uint32_t* counts_in, uint32_t* cursors,
-                                              const rt_f4* ia, const rt_f4* ib, rt_f4* hits, unsigned long long* work) {
+                                              const rt_f4* ia, const rt_f4* ib, rt_f4* hits, unsigned long long* work, void* spill) {
     const uint32_t region = blockIdx.y;
     const uint32_t n = min(counts_in[region * RT_COUNT_STRIDE], cap);   // a counter can only exceed cap after an overflow (reported by the append)
     if (n == 0) return;
@@ -215,7 +233,7 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, 
     nodes.inst_roots = sc.winst_roots;
     TracePrims<RESIDENT> prims; prims.sc = &sc; prims.lds = lds;
     prims.o_sph = plan.off_spheres; prims.o_msph = plan.off_mspheres; prims.o_rect = plan.off_rects; prims.o_box = plan.off_boxes; prims.o_inst = plan.off_instances;
-    TraceStack<WIDE> stk = make_stack<WIDE>(smem, plan.off_stack, plan.stack_cap, TB);
+    TraceStack<WIDE, SPILL> stk = MakeStack<WIDE, SPILL>::make(smem, plan, TB, spill, ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * TB + threadIdx.x, (size_t)gridDim.x * gridDim.y * TB);
 
     uint32_t* cursor = cursors + region * RT_COUNT_STRIDE;
     ia += (size_t)region * cap; ib += (size_t)region * cap; hits += (size_t)region * cap;
@@ -229,6 +247,7 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, 
     RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
     RtCounters cnt = {0, 0, 0, 0, 0, 0, 0};
     uint32_t dbg[4] = {0, 0, 0, 0};   // STATS: wave-level counts of outer iterations, refills, node-loop and leaf-loop iterations
+    uint32_t sp_max = 0, sp_steps = 0, sp_gt[6] = {0, 0, 0, 0, 0, 0};   // STATS: deepest stack; node steps in all, and with more than 4 / 6 / 8 / 10 / 12 / 16 entries on the stack
 
     for (;;) {
         unsigned long long am = __ballot(active);
@@ -263,6 +282,11 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, 
             while (rt_is_inner(tv.cur)) {
                 if (STATS) { unsigned long long ex = __ballot(true); if ((int)lane == __ffsll((long long)ex) - 1) dbg[2]++; }
                 rt_inner_step<STATS>(nodes, tv, RT_TMIN, hit, stk, &cnt);
+                if (STATS) {
+                    const uint32_t d = (uint32_t)tv.sp;
+                    sp_max = max(sp_max, d); sp_steps++;
+                    sp_gt[0] += d > 4; sp_gt[1] += d > 6; sp_gt[2] += d > 8; sp_gt[3] += d > 10; sp_gt[4] += d > 12; sp_gt[5] += d > 16;
+                }
                 { int n_in = __popcll(__ballot(rt_is_inner(tv.cur)));
                   if (WIDE4 ? (n_in * RT_NODE_LEAVE_RATIO_WIDE < (n_enter - n_in) * RT_NODE_LEAVE_DEN_WIDE) : (n_in * RT_NODE_LEAVE_RATIO < n_enter - n_in)) break; }
             }
@@ -294,6 +318,8 @@ __global__ __launch_bounds__(TB) void k_trace(RtSceneView sc, RtTracePlan plan, 
         atomicAdd(work + 4, (unsigned long long)cnt.instances); atomicAdd(work + 7, (unsigned long long)cnt.boxes);
         if (WIDE4) atomicAdd(work + 15, (unsigned long long)cnt.wnodes);
         for (int k = 0; k < 4; ++k) if (dbg[k]) atomicAdd(work + 16 + k, (unsigned long long)dbg[k]);
+        atomicMax(work + 20, (unsigned long long)sp_max); atomicAdd(work + 21, (unsigned long long)sp_steps);
+        for (int k = 0; k < 6; ++k) atomicAdd(work + 22 + k, (unsigned long long)sp_gt[k]);
     }
 }
 
@@ -313,7 +339,7 @@ struct ShadeMedia {   // medium records: the first RT_SHADE_MEDIA_LDS media from
 // contribution slot; out.alive = the path continues with the ray out.na / nb / nc.  out.postponed = the hit needs a costly
 // texture and `may_postpone` was set: nothing has been written for the ray then.
 // Tab: see RtGlobalTables; MediaSrc: see rt_media_hits.  STATS = true also counts shades per material kind into `work`.
-struct ShadeOut { bool alive, postponed; int cls; rt_f4 na, nb, nc; };
+struct ShadeOut { bool alive, postponed, resolved; int cls; rt_f4 na, nb, nc, nh; };   // resolved: nh is the scattered ray's closest surface hit
 // Classes of hits that a wave may set aside and shade together later (k_shade_lds): 0 = the material's texture tree holds a
 // Noise (Perlin turbulence, ~1300 instructions).  RT_POSTPONE_CLASSES = 2 adds dielectrics, 3 also metals (measured: not worth
 // it -- a postponed hit repeats the medium tests and the hit record, which cost more than the divergence they avoid).
@@ -322,7 +348,7 @@ struct ShadeOut { bool alive, postponed; int cls; rt_f4 na, nb, nc; };
 #endif
 template <bool STATS, class Tab, class MediaSrc>
 __device__ __forceinline__ void shade_ray(const RtSceneView& sc, const Tab& tab, const MediaSrc& msrc, const RtFrameDev& fr, int bounce,
-                                          rt_f4 a, rt_f4 b, rt_f4 c, rt_f4 h, bool may_postpone, rt_f4* contrib,
+                                          rt_f4 a, rt_f4 b, rt_f4 c, rt_f4 h, bool may_postpone, bool local_ok, rt_f4* contrib,
                                           unsigned long long* work, ShadeOut& out) {
     v3 o = mk3(a.x, a.y, a.z), d = mk3(b.x, b.y, b.z), beta = mk3(c.x, c.y, c.z);
     float time = a.w;
@@ -371,6 +397,38 @@ __device__ __forceinline__ void shade_ray(const RtSceneView& sc, const Tab& tab,
                 out.nb.x = dir.x; out.nb.y = dir.y; out.nb.z = dir.z;
                 out.nb.w = i2f(RT_HIT_KIND(hit.code) == RT_KIND_MEDIUM ? (int)RT_HIT_NONE : (int)hit.code);
                 out.nc.x = beta.x; out.nc.y = beta.y; out.nc.z = beta.z; out.nc.w = c.w;
+                // A ray that leaves a collision inside a medium whose boundary encloses a known handful of surfaces (flatten.cpp,
+                // emit_medium_locals): if it hits one that lies wholly inside the boundary, that is its closest surface hit --
+                // the same test with the same operands as the tree search would make, so the same record -- and the closest-hit
+                // kernel skips the ray.  (final_scene.yml: a third of all rays are such steps of walks inside the glass ball.)
+                if (local_ok && RT_HIT_KIND(hit.code) == RT_KIND_MEDIUM) {
+                    const int m = (int)RT_HIT_INDEX(hit.code);
+                    const rt_f4 m5 = msrc.get(m, 5);
+                    const int n_local = f2i(m5.z) & 255, inside_mask = f2i(m5.z) >> 8;
+                    if (n_local > 0) {
+                        const rt_f4 m4 = msrc.get(m, 4);
+                        RtTrav lt; rt_trav_ray(lt, sf.p, dir); lt.inst = -1; lt.sp = 0; lt.cur = RT_EMPTY_STACK;
+                        RtHit nh; nh.t = rt_inf(); nh.code = RT_HIT_NONE; nh.inst = -1;
+                        rt_leaf_test<false>(tab, f2i(m4.z), time, RT_TMIN, RT_HIT_NONE, lt, nh, nullptr);
+                        int which = nh.code != RT_HIT_NONE ? 1 : 0;
+                        if (n_local > 1) {
+                            const float t0 = nh.t;
+                            rt_leaf_test<false>(tab, f2i(m4.w), time, RT_TMIN, RT_HIT_NONE, lt, nh, nullptr);
+                            if (nh.t < t0) which = 2;
+                        }
+                        if (n_local > 2) {
+                            const float t0 = nh.t;
+                            rt_leaf_test<false>(tab, f2i(m5.w), time, RT_TMIN, RT_HIT_NONE, lt, nh, nullptr);
+                            if (nh.t < t0) which = 4;
+                        }
+                        if (which & inside_mask) {
+                            out.resolved = true;
+                            out.nh.x = nh.t; out.nh.y = i2f((int)nh.code); out.nh.z = i2f(-1); out.nh.w = 0.0f;
+                            out.nb.w = i2f((int)RT_SRC_RESOLVED);
+                            if (STATS) atomicAdd(work + 28, 1ull);
+                        }
+                    }
+                }
             }
         }
     }
@@ -385,39 +443,62 @@ __device__ __forceinline__ void shade_ray(const RtSceneView& sc, const Tab& tab,
     }
 }
 __device__ __forceinline__ void shade_out_clear(ShadeOut& out) {
-    out.alive = false; out.postponed = false; out.cls = 0;
+    out.alive = false; out.postponed = false; out.resolved = false; out.cls = 0;
     out.na.x = out.na.y = out.na.z = out.na.w = out.nb.x = out.nb.y = out.nb.z = out.nb.w = out.nc.x = out.nc.y = out.nc.z = out.nc.w = 0.0f;
 }
-// Append of the scattered rays of one wave to the output queue: one atomic per wave, slot = base + rank among the live
-// lanes (ballot + mbcnt).  Wave-uniform control flow only.  Returns whether any lane appended; the wave has then waited
-// for every vector memory operation it had issued before this call (the atomic's result is the last of them).
-__device__ __forceinline__ bool shade_append(const ShadeOut& out, uint32_t* n_out_ptr, uint32_t* overflow, uint32_t cap, rt_f4* oa, rt_f4* ob, rt_f4* oc) {
-    unsigned long long mask = __ballot(out.alive);
-    if (!mask) return false;
-    uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    uint32_t slot0 = 0;
-    if (out.alive && rank == 0) slot0 = atomicAdd(n_out_ptr, (uint32_t)__popcll(mask));
+// Append of the scattered rays of one wave to the output region: rays for the closest-hit kernel from the front, settled rays
+// (out.resolved, with their hit record) from the back; one atomic per wave and end, slot = base + rank among the lanes of that
+// kind (ballot + mbcnt).  Wave-uniform control flow only.  Returns whether any lane appended; the wave has then waited for every
+// vector memory operation it had issued before this call (the atomics' results are the last of them).
+__device__ __forceinline__ bool shade_append(const ShadeOut& out, uint32_t* n_out_ptr, uint32_t* n_back_ptr, uint32_t* overflow, uint32_t cap, rt_f4* oa, rt_f4* ob,
+                                             rt_f4* oc, rt_f4* oh) {
+    const bool to_back = out.alive && out.resolved, to_front = out.alive && !out.resolved;
+    const unsigned long long mf = __ballot(to_front), mb = __ballot(to_back);
+    if (!(mf | mb)) return false;
+    const uint32_t rank_f = __builtin_amdgcn_mbcnt_hi((uint32_t)(mf >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mf, 0u));
+    const uint32_t rank_b = __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
+    uint32_t f0 = 0, b0 = 0;
+    if (to_front && rank_f == 0) f0 = atomicAdd(n_out_ptr, (uint32_t)__popcll(mf));
+    if (to_back && rank_b == 0) b0 = atomicAdd(n_back_ptr, (uint32_t)__popcll(mb));     // both in flight before the wait
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    slot0 = __shfl(slot0, __ffsll((long long)mask) - 1);
+    if (mf) f0 = __shfl(f0, __ffsll((long long)mf) - 1);
+    if (mb) b0 = __shfl(b0, __ffsll((long long)mb) - 1);
     // The capacity bound holds by construction (see the top of the file); should it ever fail, the ray is dropped, the
-    // overflow counter says so and the render call returns RT_ERR_INTERNAL instead of a biased image.
-    if (out.alive && slot0 + rank >= cap) atomicAdd(overflow, 1u);
+    // overflow counter says so and the render call returns RT_ERR_INTERNAL instead of a biased image.  (That the two ends have
+    // not met is checked by the kernels that read the region.)
+    const uint32_t pos = to_back ? b0 + rank_b : f0 + rank_f;
+    if (out.alive && pos >= cap) atomicAdd(overflow, 1u);
     else if (out.alive) {
-        uint32_t slot = slot0 + rank;
+        const uint32_t slot = to_back ? cap - 1u - pos : pos;
         *reinterpret_cast<float4*>(oa + slot) = make_float4(out.na.x, out.na.y, out.na.z, out.na.w);
         *reinterpret_cast<float4*>(ob + slot) = make_float4(out.nb.x, out.nb.y, out.nb.z, out.nb.w);
         *reinterpret_cast<float4*>(oc + slot) = make_float4(out.nc.x, out.nc.y, out.nc.z, out.nc.w);
+        if (to_back) *reinterpret_cast<float4*>(oh + slot) = make_float4(out.nh.x, out.nh.y, out.nh.z, out.nh.w);   // the next bounce's hit record
     }
     return true;
 }
+// The two parts of an input region as one index range: entry v of n_front + n_back is slot v of the front part, or slot
+// cap - 1 - (v - n_front) of the back part.  *n_front is in, n_back is clamped so that the parts cannot overlap (an overlap is
+// an overflow and is reported).
+__device__ __forceinline__ uint32_t region_back_count(const uint32_t* back_in, uint32_t region, uint32_t n_front, uint32_t cap, uint32_t* overflow) {
+    if (!back_in) return 0u;
+    uint32_t n_back = back_in[region * RT_COUNT_STRIDE];
+    if (n_back > cap - n_front) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(overflow, 1u);
+        n_back = cap - n_front;
+    }
+    return n_back;
+}
+__device__ __forceinline__ uint32_t region_slot(uint32_t v, uint32_t n_front, uint32_t cap) { return v < n_front ? v : cap - 1u - (v - n_front); }
 
 // One ray per lane, grid-stride, tables from global memory (any scene).  The input queue region is blockIdx.y.
 template <bool STATS>
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev fr, int bounce, uint32_t cap, const uint32_t* counts_in,
                                                     uint32_t* counts_out, uint32_t* overflow, const rt_f4* ia, const rt_f4* ib, const rt_f4* ic,
                                                     const rt_f4* hits, rt_f4* oa, rt_f4* ob, rt_f4* oc, rt_f4* contrib,
-                                                    unsigned long long* work) {
-    const uint32_t n = min(counts_in[blockIdx.y * RT_COUNT_STRIDE], cap);
+                                                    unsigned long long* work, rt_f4* hits_out, const uint32_t* back_in, uint32_t* back_out) {
+    const uint32_t n_front = min(counts_in[blockIdx.y * RT_COUNT_STRIDE], cap);
+    const uint32_t n = n_front + region_back_count(back_in, blockIdx.y, n_front, cap, overflow);
     if (blockIdx.x * RT_BLOCK >= n) return;
     // the medium records are the same for every ray: one LDS copy per block instead of a chain of fetches per ray
     __shared__ __align__(16) rt_f4 s_media[RT_SHADE_MEDIA_LDS * RT_MEDIUM_F4];
@@ -429,12 +510,15 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev f
     uint32_t* n_out_ptr = counts_out + out_shard * RT_COUNT_STRIDE;
     ia += (size_t)blockIdx.y * cap; ib += (size_t)blockIdx.y * cap; ic += (size_t)blockIdx.y * cap; hits += (size_t)blockIdx.y * cap;
     oa += (size_t)out_shard * cap; ob += (size_t)out_shard * cap; oc += (size_t)out_shard * cap;
+    const bool local_ok = hits_out != nullptr && back_out != nullptr;     // the next bounce's hit stream and back counters, for rays whose closest hit is settled here
+    uint32_t* n_back_ptr = local_ok ? back_out + out_shard * RT_COUNT_STRIDE : nullptr;
+    if (local_ok) hits_out += (size_t)out_shard * cap;
 
     // Returns true when the hit was postponed.  Called from wave-uniform control flow only (the append votes over the wave).
     auto shade = [&](uint32_t i, bool valid, bool may_postpone) -> bool {
         ShadeOut out; shade_out_clear(out);
-        if (valid) shade_ray<STATS>(sc, tab, msrc, fr, bounce, ld4(ia + i), ld4(ib + i), bounce == 1 ? rt_first_c(blockIdx.y, i) : ld4(ic + i), ld4(hits + i), may_postpone, contrib, work, out);
-        shade_append(out, n_out_ptr, overflow, cap, oa, ob, oc);
+        if (valid) shade_ray<STATS>(sc, tab, msrc, fr, bounce, ld4(ia + i), ld4(ib + i), bounce == 1 ? rt_first_c(blockIdx.y, i) : ld4(ic + i), ld4(hits + i), may_postpone, local_ok, contrib, work, out);
+        shade_append(out, n_out_ptr, n_back_ptr, overflow, cap, oa, ob, oc, hits_out);
         return out.postponed;
     };
 
@@ -447,8 +531,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev f
     const bool may_postpone = sc.n_perlin > 0;
     uint32_t n_later = 0;                                              // wave-uniform
     for (uint32_t base = blockIdx.x * RT_BLOCK; base < n; base += gridDim.x * RT_BLOCK) {
-        uint32_t i = base + threadIdx.x;
-        bool post = shade(i, i < n, may_postpone);
+        const uint32_t v = base + threadIdx.x;
+        const uint32_t i = region_slot(min(v, n - 1u), n_front, cap);   // slot of entry v
+        bool post = shade(i, v < n, may_postpone);
         unsigned long long pm = __ballot(post);
         if (pm) {
             uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
@@ -541,8 +626,10 @@ __device__ __forceinline__ void shade_stage(const rt_f4* ia, const rt_f4* ib, co
 template <bool FUSED, bool PROBE = false>
 __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan pl, RtFrameDev fr, int bounce, uint32_t cap, const uint32_t* counts_in,
                                                     uint32_t* counts_out, uint32_t* overflow, const rt_f4* ia, const rt_f4* ib, const rt_f4* ic,
-                                                    const rt_f4* hits, rt_f4* oa, rt_f4* ob, rt_f4* oc, rt_f4* contrib) {
-    const uint32_t n = min(counts_in[blockIdx.y * RT_COUNT_STRIDE], cap);
+                                                    const rt_f4* hits, rt_f4* oa, rt_f4* ob, rt_f4* oc, rt_f4* contrib, rt_f4* hits_out,
+                                                    const uint32_t* back_in, uint32_t* back_out) {
+    const uint32_t n_front = min(counts_in[blockIdx.y * RT_COUNT_STRIDE], cap);
+    const uint32_t n = n_front + region_back_count(back_in, blockIdx.y, n_front, cap, overflow);
     if (blockIdx.x * 1024u >= n) return;
     extern __shared__ __align__(16) unsigned char smem[];
     {   // tables -> LDS
@@ -571,6 +658,9 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
     uint32_t* n_out_ptr = counts_out + out_shard * RT_COUNT_STRIDE;
     ia += (size_t)blockIdx.y * cap; ib += (size_t)blockIdx.y * cap; ic += (size_t)blockIdx.y * cap; hits += (size_t)blockIdx.y * cap;
     oa += (size_t)out_shard * cap; ob += (size_t)out_shard * cap; oc += (size_t)out_shard * cap;
+    const bool local_ok = !FUSED && hits_out != nullptr && back_out != nullptr;
+    uint32_t* n_back_ptr = local_ok ? back_out + out_shard * RT_COUNT_STRIDE : nullptr;
+    if (local_ok) hits_out += (size_t)out_shard * cap;
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     lds_f4* stage = tab.lds + pl.off_stage + wave * 256u;
@@ -578,8 +668,9 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
     const bool may_postpone = sc.n_perlin > 0 || RT_POSTPONE_CLASSES > 1;
     const uint32_t stride = gridDim.x * 1024u;
     uint32_t base = blockIdx.x * 1024u + wave * 64u;                   // wave-uniform
-    TraceStack<true> stk;   // FUSED
-    stk.base = (lds_int*)(tab.lds + pl.off_stack) + threadIdx.x; stk.depth = pl.stack_cap; stk.stride = 1024;
+    TraceStack<true, false> stk;   // FUSED
+    stk.base = (lds_int*)(tab.lds + pl.off_stack) + threadIdx.x; stk.depth = pl.stack_cap; stk.total = pl.stack_cap; stk.stride = 1024;
+    stk.spill = nullptr; stk.spill_stride = 0;
     // the closest hit of ray (a, b) as the record k_trace would have written
     auto closest = [&](rt_f4 a, rt_f4 b) -> rt_f4 {
         RtHit hit; hit.t = rt_inf(); hit.code = RT_HIT_NONE; hit.inst = -1;
@@ -592,7 +683,7 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
         return h;
     };
     const bool with_c = bounce != 1;                                   // camera rays: see rt_first_c
-    if (base < n) shade_stage<FUSED>(ia, ib, ic, hits, min(base + lane, n - 1u), stage, with_c);
+    if (base < n) shade_stage<FUSED>(ia, ib, ic, hits, region_slot(min(base + lane, n - 1u), n_front, cap), stage, with_c);
     bool landed = false;                                               // the staged records are known to have arrived
     // One loop body, one inlined copy of the shading code: an iteration shades either 64 postponed hits of one class (as soon
     // as a class has that many, and whatever is left once the queue is exhausted) or the wave's next 64 staged queue entries.
@@ -618,13 +709,14 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
             if (valid) { a = ld4(ia + i); b = ld4(ib + i); if (with_c) c = ld4(ic + i); if (!FUSED) h = ld4(hits + i); }
             landed = true;                                             // these loads were issued after the staging and are waited for below
         } else {
-            i = base + lane;
+            const uint32_t v = base + lane;                            // entry of the region's two parts taken as one range
+            i = region_slot(min(v, n - 1u), n_front, cap);
             if (!landed) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             a = lds_ld4(stage + lane); b = lds_ld4(stage + 64 + lane); if (with_c) c = lds_ld4(stage + 128 + lane);
             if (!FUSED) h = lds_ld4(stage + 192 + lane);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // the records are in registers, the staging area is free
-            if (base + stride < n) shade_stage<FUSED>(ia, ib, ic, hits, min(i + stride, n - 1u), stage, with_c);
-            valid = i < n; may_post = may_postpone;
+            if (base + stride < n) shade_stage<FUSED>(ia, ib, ic, hits, region_slot(min(v + stride, n - 1u), n_front, cap), stage, with_c);
+            valid = v < n; may_post = may_postpone;
             base += stride;
             landed = false;
         }
@@ -633,9 +725,9 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
         if (valid) {
             if (FUSED) h = closest(a, b);
             if (FUSED && PROBE) *reinterpret_cast<float4*>(const_cast<rt_f4*>(hits) + i) = make_float4(h.x, h.y, h.z, h.w);
-            shade_ray<false>(sc, tab, tab, fr, bounce, a, b, c, h, may_post, contrib, nullptr, out);
+            shade_ray<false>(sc, tab, tab, fr, bounce, a, b, c, h, may_post, local_ok, contrib, nullptr, out);
         }
-        if (shade_append(out, n_out_ptr, overflow, cap, oa, ob, oc)) landed = true;
+        if (shade_append(out, n_out_ptr, n_back_ptr, overflow, cap, oa, ob, oc, hits_out)) landed = true;
         if (may_post) {
 #pragma unroll
             for (int k = 0; k < RT_POSTPONE_CLASSES; ++k) {
@@ -672,11 +764,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const rt_f4* contrib, R
 
 // folded[row] = sum over the regions of counts[row][region]: the rays that entered bounce `row` (row 0: the overflow counter),
 // so that the host reads back 8 bytes per bounce instead of the counter lines.
-__global__ __launch_bounds__(RT_BLOCK) void k_fold_counts(const uint32_t* counts, int rows, unsigned long long* folded) {
+__global__ __launch_bounds__(RT_BLOCK) void k_fold_counts(const uint32_t* counts, const uint32_t* back, int rows, unsigned long long* folded) {
     int row = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (row >= rows) return;
     unsigned long long sum = 0;
-    for (int sh = 0; sh < RT_SHARDS; ++sh) sum += counts[((size_t)row * RT_SHARDS + sh) * RT_COUNT_STRIDE];
+    for (int sh = 0; sh < RT_SHARDS; ++sh) {
+        sum += counts[((size_t)row * RT_SHARDS + sh) * RT_COUNT_STRIDE];
+        if (back && row > 0) sum += back[((size_t)row * RT_SHARDS + sh) * RT_COUNT_STRIDE];   // both parts of a region hold rays of the bounce
+    }
     folded[row] = sum;
 }
 
@@ -781,9 +876,14 @@ static __device__ __align__(256) unsigned char g_noalloc_scratch[kNaScratchBytes
 // static device array instead.
 struct Workspace {
     size_t paths = 0, cap = 0;             // paths it was sized for; slots per queue region
-    rt_f4 *qa[2] = {nullptr, nullptr}, *qb[2] = {nullptr, nullptr}, *qc[2] = {nullptr, nullptr}, *contrib = nullptr, *hits = nullptr;
-    // counts: `rows` rows of [region] queue sizes (row b = rays entering bounce b; word 0 of row 0, which no bounce uses, is the
-    // overflow counter), then `rows` rows of k_trace cursors.  folded: per row, the sum over the regions (k_fold_counts).
+    rt_f4 *qa[2] = {nullptr, nullptr}, *qb[2] = {nullptr, nullptr}, *qc[2] = {nullptr, nullptr}, *contrib = nullptr;
+    // hit records of the rays entering bounce b: hits[b & 1].  Two streams because a shading launch reads this bounce's records while
+    // it writes those of the next bounce's rays whose closest hit it settles itself (shade_ray); hits[1] == null: one stream, and no
+    // ray is settled there.
+    rt_f4* hits[2] = {nullptr, nullptr};
+    // counts: `rows` rows of [region] queue sizes (row b = rays entering bounce b from the front of the regions; word 0 of row 0,
+    // which no bounce uses, is the overflow counter), then `rows` rows of k_trace cursors, then `rows` rows of the sizes of the
+    // regions' back parts (workspaces with two hit streams only).  folded: per row, the sum over the regions (k_fold_counts).
     uint32_t* counts = nullptr;
     unsigned long long* folded = nullptr;
     int rows = 0;
@@ -805,6 +905,8 @@ struct RtScene {
     double bvh_build_seconds = 0.0;        // device time of that build
     int top_first = 0;                     // first node of the region k_trace should keep in LDS (see plan_trace)
     int trace_block = 1024;                // threads per k_trace block (1024, or 256 where a block cannot have 160 KB of LDS)
+    bool has_local_media = false;          // some medium record lists the surfaces inside its boundary (flatten.cpp, emit_medium_locals)
+    void* stack_spill = nullptr;           // k_trace: global part of the traversal stacks (entries beyond plan.stack_cap), [entry][thread of the grid]
     bool shade_lds = false;                // the shading tables fit one CU's LDS: k_shade_lds instead of k_shade
     bool shade_fused = false;              // ... and the BVH is a handful of nodes: k_shade_lds<true> finds the closest hits too, k_trace is not run
     RtShadePlan shade_plan;                // k_shade_lds: layout of the block's LDS
@@ -822,21 +924,24 @@ static const int kLdsBudget = 160 * 1024 - 512;   // dynamic LDS a 1024-thread b
 // k_trace comes in two block shapes: 1024 threads (one block per CU; its 16 waves share one LDS copy of the scene) and,
 // where a workgroup cannot have that much LDS, 256 threads (four blocks per CU, each with a 40 KB plan).
 static void launch_trace(RtScene* s, const Workspace& ws, bool stats, hipStream_t st, uint32_t cap, const uint32_t* cin, uint32_t* cursors,
-                         const rt_f4* qa, const rt_f4* qb) {
+                         const rt_f4* qa, const rt_f4* qb, rt_f4* hits) {
     dim3 grid(s->trace_gx, RT_SHARDS);
-#define RT_LAUNCH_TRACE(TB_, WIDE_, RES_, W4_)                                                                                \
+    const bool spill = s->plan.stack_total > s->plan.stack_cap;   // only the two forms below are built with a spilling stack (plan_trace)
+#define RT_LAUNCH_TRACE(TB_, WIDE_, RES_, W4_, SP_)                                                                           \
     do {                                                                                                                      \
-        if (stats) hipLaunchKernelGGL((k_trace<true, TB_, WIDE_, RES_, W4_>), grid, dim3(TB_), (size_t)s->lds_bytes, st, s->view, s->plan, cap, \
-                                      cin, cursors, qa, qb, ws.hits, ws.work);                                                \
-        else hipLaunchKernelGGL((k_trace<false, TB_, WIDE_, RES_, W4_>), grid, dim3(TB_), (size_t)s->lds_bytes, st, s->view, s->plan, cap,      \
-                                cin, cursors, qa, qb, ws.hits, ws.work);                                                      \
+        if (stats) hipLaunchKernelGGL((k_trace<true, TB_, WIDE_, RES_, W4_, SP_>), grid, dim3(TB_), (size_t)s->lds_bytes, st, s->view, s->plan, cap, \
+                                      cin, cursors, qa, qb, hits, ws.work, s->stack_spill);                                   \
+        else hipLaunchKernelGGL((k_trace<false, TB_, WIDE_, RES_, W4_, SP_>), grid, dim3(TB_), (size_t)s->lds_bytes, st, s->view, s->plan, cap,      \
+                                cin, cursors, qa, qb, hits, ws.work, s->stack_spill);                                         \
     } while (0)
-    if (s->plan.wide4 && s->plan.resident) RT_LAUNCH_TRACE(1024, true, true, true);
-    else if (s->plan.wide4) RT_LAUNCH_TRACE(1024, true, false, true);
-    else if (s->trace_block == 1024 && s->plan.resident) RT_LAUNCH_TRACE(1024, false, true, false);
-    else if (s->trace_block == 1024 && !s->plan.wide_stack) RT_LAUNCH_TRACE(1024, false, false, false);
-    else if (s->trace_block == 1024) RT_LAUNCH_TRACE(1024, true, false, false);
-    else RT_LAUNCH_TRACE(256, true, false, false);
+    if (s->plan.wide4 && s->plan.resident) RT_LAUNCH_TRACE(1024, true, true, true, false);
+    else if (s->plan.wide4 && spill) RT_LAUNCH_TRACE(1024, true, false, true, true);
+    else if (s->plan.wide4) RT_LAUNCH_TRACE(1024, true, false, true, false);
+    else if (s->trace_block == 1024 && s->plan.resident && spill) RT_LAUNCH_TRACE(1024, false, true, false, true);
+    else if (s->trace_block == 1024 && s->plan.resident) RT_LAUNCH_TRACE(1024, false, true, false, false);
+    else if (s->trace_block == 1024 && !s->plan.wide_stack) RT_LAUNCH_TRACE(1024, false, false, false, false);
+    else if (s->trace_block == 1024) RT_LAUNCH_TRACE(1024, true, false, false, false);
+    else RT_LAUNCH_TRACE(256, true, false, false, false);
 #undef RT_LAUNCH_TRACE
 }
 
@@ -845,10 +950,13 @@ static void launch_trace(RtScene* s, const Workspace& ws, bool stats, hipStream_
 // is used and the room left goes to whole primitive arrays; otherwise 32-bit entries and a breadth-first node prefix.
 // wide4: the plan is for the 4-wide tree (n_nodes of sc.wnodes): 32-bit stack entries always, and when all nodes fit, primitive
 // arrays beside them as in the narrow form.
-static void fill_plan(const RtSceneView& v, int n_nodes, int max_stack, int threads, int budget, int refill_lanes, bool allow_narrow, bool wide4,
+// lds_entries > 0: only that many stack entries per lane are kept in LDS, deeper ones spill to global memory.
+static void fill_plan(const RtSceneView& v, int n_nodes, int max_stack, int lds_entries, int threads, int budget, int refill_lanes, bool allow_narrow, bool wide4,
                       int top_first, RtTracePlan& pl, int& lds_bytes) {
-    const int stack_cap = std::max(1, max_stack);
-    pl.stack_cap = stack_cap; pl.refill_lanes = refill_lanes; pl.resident = 0; pl.first_lds = 0; pl.wide4 = wide4 ? 1 : 0;
+    pl.stack_total = std::max(1, max_stack);
+    const int stack_cap = lds_entries > 0 ? std::min(pl.stack_total, lds_entries) : pl.stack_total;
+    pl.stack_cap = stack_cap; pl.refill_lanes = refill_lanes; pl.resident = 0;
+ pl.first_lds = 0; pl.wide4 = wide4 ? 1 : 0;
     pl.off_spheres = pl.off_mspheres = pl.off_rects = pl.off_boxes = pl.off_instances = -1;
     const int narrow = stack_cap * threads * 2, wide = stack_cap * threads * 4;
     const int stack_bytes = wide4 ? wide : narrow;
@@ -891,20 +999,35 @@ static int plan_trace(RtScene* s) {
     const char* env_w = std::getenv("RT_TRACE_WIDE_STACK"); const bool narrow_ok = !(env_w && std::atoi(env_w) != 0);
     int blocks_per_cu = 1;
     bool planned = false;
+    // RT_TRACE_STACK_LDS = n: only n stack entries per lane are kept in LDS, deeper ones spill to global memory (for a scene
+    // resident in LDS, and for the 4-wide tree of one that is not).  Measured: the worst case is far above the depth in use (23
+    // against 15 reached on final_scene.yml, 0.07 % of the node steps with more than 8 entries pending; 36 against 19 on the 1M-sphere
+    // scene), but the LDS it frees buys little -- 12 entries in LDS let 1700 instead of 200 top nodes of the 1M-sphere scene
+    // stay there for +0.5 % -- and the spill path costs the node loop a branch, so the default keeps every entry in LDS.
+    int stack_lds = 0;
+    if (const char* e = std::getenv("RT_TRACE_STACK_LDS")) stack_lds = std::max(0, std::atoi(e));
     if (want == 1024 && s->flat.max_stack * 1024 * 4 + 64 <= kLdsBudget) {
-        fill_plan(s->view, s->view.n_nodes, s->flat.max_stack, 1024, kLdsBudget, refill, narrow_ok, false, s->top_first, s->plan, s->lds_bytes);
+        fill_plan(s->view, s->view.n_nodes, s->flat.max_stack, 0, 1024, kLdsBudget, refill, narrow_ok, false, s->top_first, s->plan, s->lds_bytes);
+        if (stack_lds > 0 && s->plan.resident)
+            fill_plan(s->view, s->view.n_nodes, s->flat.max_stack, stack_lds, 1024, kLdsBudget, refill, narrow_ok, false, s->top_first, s->plan, s->lds_bytes);
         // The 4-wide quantised tree replaces the binary one when the binary node array does not fit the LDS (a ray then makes
         // half as many dependent fetches from L2 / HBM), provided its deeper stack fits.  RT_TRACE_BVH4 = 1 / 0 forces the choice.
         bool want_wide = !s->plan.resident && s->plan.wide_stack;
         if (const char* e = std::getenv("RT_TRACE_BVH4")) want_wide = std::atoi(e) != 0;
-        if (want_wide && s->view.n_wnodes > 0 && s->view.wmax_stack * 1024 * 4 + 64 <= kLdsBudget)
-            fill_plan(s->view, s->view.n_wnodes, s->view.wmax_stack, 1024, kLdsBudget, refill_wide, false, true, 0, s->plan, s->lds_bytes);
+        if (want_wide && s->view.n_wnodes > 0 && s->view.wmax_stack * 1024 * 4 + 64 <= kLdsBudget) {
+            fill_plan(s->view, s->view.n_wnodes, s->view.wmax_stack, 0, 1024, kLdsBudget, refill_wide, false, true, 0, s->plan, s->lds_bytes);
+            if (stack_lds > 0 && !s->plan.resident)
+                fill_plan(s->view, s->view.n_wnodes, s->view.wmax_stack, stack_lds, 1024, kLdsBudget, refill_wide, false, true, 0, s->plan, s->lds_bytes);
+        }
+        const bool spill = s->plan.stack_total > s->plan.stack_cap;
         const void* fns[2];
-        if (s->plan.wide4 && s->plan.resident) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, true, true>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, true, true>); }
-        else if (s->plan.wide4) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, false, true>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, false, true>); }
-        else if (s->plan.resident) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, false, true, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, false, true, false>); }
-        else if (!s->plan.wide_stack) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, false, false, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, false, false, false>); }
-        else { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, false, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, false, false>); }
+        if (s->plan.wide4 && s->plan.resident) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, true, true, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, true, true, false>); }
+        else if (s->plan.wide4 && spill) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, false, true, true>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, false, true, true>); }
+        else if (s->plan.wide4) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, false, true, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, false, true, false>); }
+        else if (s->plan.resident && spill) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, false, true, false, true>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, false, true, false, true>); }
+        else if (s->plan.resident) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, false, true, false, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, false, true, false, false>); }
+        else if (!s->plan.wide_stack) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, false, false, false, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, false, false, false, false>); }
+        else { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, false, false, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, false, false, false>); }
         // the limit is a property of the kernel, not of this scene: always the whole budget, so that a scene created
         // later with a smaller plan does not lower it for this one
         hipError_t e = hipFuncSetAttribute(fns[0], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget);
@@ -913,14 +1036,20 @@ static int plan_trace(RtScene* s) {
         else (void)hipGetLastError();   // this device does not give one workgroup that much LDS: use the small blocks
     }
     if (!planned) {
-        fill_plan(s->view, s->view.n_nodes, s->flat.max_stack, 256, 40 * 1024 - 128, refill, false, false, s->top_first, s->plan, s->lds_bytes);
+        fill_plan(s->view, s->view.n_nodes, s->flat.max_stack, 0, 256, 40 * 1024 - 128, refill, false, false, s->top_first, s->plan, s->lds_bytes);
         s->trace_block = 256; blocks_per_cu = 4;
         if (s->lds_bytes > 48 * 1024) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, 256, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, 256, true, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<false, 256, true, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_trace<true, 256, true, false, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, s->lds_bytes));
         }
     }
     s->trace_gx = (unsigned)std::max(1, (std::max(1, s->n_cu) * blocks_per_cu + RT_SHARDS - 1) / RT_SHARDS);
+    if (s->plan.stack_total > s->plan.stack_cap) {   // the global part of the stacks: [entry][thread of the grid]
+        const size_t gthreads = (size_t)s->trace_gx * RT_SHARDS * (size_t)s->trace_block;
+        const size_t bytes = (size_t)(s->plan.stack_total - s->plan.stack_cap) * gthreads * (s->plan.wide_stack ? 4 : 2);
+        HIP_TRY(hipMalloc(&s->stack_spill, bytes));
+        s->allocs.push_back(s->stack_spill); s->device_bytes += bytes;
+    }
     return RT_OK;
 }
 
@@ -1009,8 +1138,8 @@ static int upload(RtScene* s, const std::vector<T>& v, const T** out) {
 static void free_queues(Workspace& w) {
     for (int i = 0; i < 2; ++i) { if (w.qa[i]) (void)hipFree(w.qa[i]); if (w.qb[i]) (void)hipFree(w.qb[i]); if (w.qc[i]) (void)hipFree(w.qc[i]); w.qa[i] = w.qb[i] = w.qc[i] = nullptr; }
     if (w.contrib) (void)hipFree(w.contrib);
-    if (w.hits) (void)hipFree(w.hits);
-    w.hits = nullptr; w.contrib = nullptr; w.paths = 0; w.cap = 0;
+    for (int i = 0; i < 2; ++i) { if (w.hits[i]) (void)hipFree(w.hits[i]); w.hits[i] = nullptr; }
+    w.contrib = nullptr; w.paths = 0; w.cap = 0;
 }
 // Slots per queue region for a pass of n_paths paths (see the capacity argument at the top of the file).
 static size_t region_cap(size_t n_paths) {
@@ -1031,7 +1160,7 @@ static DeviceWorkspace* device_workspace(int device) {
 static int ensure_workspace(RtScene* s, Workspace& w, size_t n_paths) {
     if (!w.counts) {
         w.rows = RT_MAX_BOUNCES + 2;
-        HIP_TRY(hipMalloc((void**)&w.counts, (size_t)2 * w.rows * RT_SHARDS * RT_COUNT_STRIDE * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&w.counts, (size_t)3 * w.rows * RT_SHARDS * RT_COUNT_STRIDE * sizeof(uint32_t)));
         HIP_TRY(hipMalloc((void**)&w.folded, (size_t)w.rows * sizeof(unsigned long long)));
     }
     if (!w.work) { HIP_TRY(hipMalloc((void**)&w.work, 32 * sizeof(unsigned long long))); }
@@ -1049,7 +1178,7 @@ static int ensure_workspace(RtScene* s, Workspace& w, size_t n_paths) {
         HIP_TRY(hipMalloc((void**)&w.qc[i], cap * RT_SHARDS * sizeof(rt_f4)));
     }
     HIP_TRY(hipMalloc((void**)&w.contrib, n_paths * sizeof(rt_f4)));
-    HIP_TRY(hipMalloc((void**)&w.hits, cap * RT_SHARDS * sizeof(rt_f4)));
+    for (int i = 0; i < 2; ++i) HIP_TRY(hipMalloc((void**)&w.hits[i], cap * RT_SHARDS * sizeof(rt_f4)));
     w.paths = n_paths; w.cap = cap;
     return RT_OK;
 }
@@ -1062,7 +1191,7 @@ static Workspace static_workspace(unsigned char* base) {
     w.folded = (unsigned long long*)take(kNaFoldedBytes);
     w.contrib = (rt_f4*)take(kNaContribBytes);
     for (int i = 0; i < 2; ++i) { w.qa[i] = (rt_f4*)take(kNaStreamBytes); w.qb[i] = (rt_f4*)take(kNaStreamBytes); w.qc[i] = (rt_f4*)take(kNaStreamBytes); }
-    w.hits = (rt_f4*)take(kNaStreamBytes);
+    w.hits[0] = (rt_f4*)take(kNaStreamBytes); w.hits[1] = nullptr;
     w.rows = (int)kNaRows; w.paths = RT_NOALLOC_MAX_PATHS; w.cap = kNaCap; w.work = nullptr;
     return w;
 }
@@ -1201,6 +1330,7 @@ int rt_scene_create_ex(const RtBuilder* b, RtObj world, int device, int flags, R
         if ((r = upload(s, f.perlin_perm, &v.perlin_perm))) return r;
         if ((r = upload(s, f.boxes, &v.boxes))) return r;
         s->view = v;
+        for (size_t m = 0; m * RT_MEDIUM_F4 < f.media.size(); ++m) { int32_t nl; std::memcpy(&nl, &f.media[m * RT_MEDIUM_F4 + 5].z, 4); if ((nl & 255) > 0) s->has_local_media = true; }
         if ((r = plan_trace(s))) return r;
         if ((r = plan_shade(s))) return r;
         return RT_OK;
@@ -1264,6 +1394,11 @@ static int render_passes(RtScene* s, const Workspace& ws, const RtCamera* cam, c
         while ((int)s->ev_trace.size() < 2 * p->max_depth) { hipEvent_t e = nullptr; HIP_TRY(hipEventCreate(&e)); s->ev_trace.push_back(e); }
     }
     const bool debug_work = ws.work && std::getenv("RT_DEBUG_WORK") != nullptr;
+    // rays that leave a collision inside a medium and hit a surface known to lie inside its boundary skip the closest-hit kernel
+    // (shade_ray); RT_LOCAL_MEDIA=0 sends every ray through the tree
+    const char* env_local = std::getenv("RT_LOCAL_MEDIA");
+    const bool local_media = s->has_local_media && !(env_local && std::atoi(env_local) == 0) && ws.hits[1] && !(s->shade_fused && !instrumented);
+    uint32_t* back = local_media ? ws.counts + (size_t)2 * ws.rows * row_words : nullptr;   // sizes of the regions' back parts, [bounce][region]
     if (instrumented || debug_work) HIP_TRY(hipMemsetAsync(ws.work, 0, 32 * sizeof(unsigned long long), st));
 
     for (int done = 0; done < p->spp;) {
@@ -1272,6 +1407,7 @@ static int render_passes(RtScene* s, const Workspace& ws, const RtCamera* cam, c
         fr.spp_chunk = chunk; fr.sample_base = p->sample_offset + done;
         HIP_TRY(hipMemsetAsync(ws.counts, 0, counts_bytes, st));
         HIP_TRY(hipMemsetAsync(ws.counts + (size_t)ws.rows * row_words, 0, counts_bytes, st));
+        if (back) HIP_TRY(hipMemsetAsync(back, 0, counts_bytes, st));
         int grid = (int)std::min<size_t>(((size_t)n_paths + RT_BLOCK - 1) / RT_BLOCK, (size_t)grid_cap);
         hipLaunchKernelGGL(k_raygen, dim3(grid), dim3(RT_BLOCK), 0, st, cd, fr, n_paths, cap, ws.counts + row_words, overflow, ws.qa[0], ws.qb[0], ws.contrib);
         // bounce grid: x = blocks per region (a multiple of RT_SHARDS, see the capacity argument above), y = region
@@ -1289,20 +1425,24 @@ static int render_passes(RtScene* s, const Workspace& ws, const RtCamera* cam, c
             uint32_t* cursors = ws.counts + (size_t)(ws.rows + b) * row_words;
             if (time_trace) HIP_TRY(hipEventRecord(s->ev_trace[2 * (b - 1)], st));
             const bool fused = s->shade_fused && !instrumented;
-            if (!fused) launch_trace(s, ws, instrumented, st, cap, cin, cursors, ws.qa[in], ws.qb[in]);
+            rt_f4* hits_in = ws.hits[1] ? ws.hits[b & 1] : ws.hits[0];
+            rt_f4* hits_out = local_media ? ws.hits[(b + 1) & 1] : nullptr;   // see shade_ray: rays whose closest hit the shading kernel settles
+            const uint32_t* back_in = back ? back + (size_t)b * row_words : nullptr;
+            uint32_t* back_out = back ? back + (size_t)(b + 1) * row_words : nullptr;
+            if (!fused) launch_trace(s, ws, instrumented, st, cap, cin, cursors, ws.qa[in], ws.qb[in], hits_in);
             if (time_trace) HIP_TRY(hipEventRecord(s->ev_trace[2 * (b - 1) + 1], st));
             if (instrumented)
-                hipLaunchKernelGGL(k_shade<true>, bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, cin, cout, overflow, ws.qa[in], ws.qb[in], ws.qc[in], ws.hits,
-                                   ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib, ws.work);
+                hipLaunchKernelGGL(k_shade<true>, bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, cin, cout, overflow, ws.qa[in], ws.qb[in], ws.qc[in], hits_in,
+                                   ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib, ws.work, hits_out, back_in, back_out);
             else if (fused)
                 hipLaunchKernelGGL(k_shade_lds<true>, lgrid, dim3(1024), (size_t)s->shade_lds_bytes, st, s->view, s->shade_plan, fr, b, cap, cin, cout, overflow,
-                                   ws.qa[in], ws.qb[in], ws.qc[in], ws.hits, ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib);
+                                   ws.qa[in], ws.qb[in], ws.qc[in], hits_in, ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib, hits_out, back_in, back_out);
             else if (s->shade_lds)
                 hipLaunchKernelGGL(k_shade_lds<false>, lgrid, dim3(1024), (size_t)s->shade_lds_bytes, st, s->view, s->shade_plan, fr, b, cap, cin, cout, overflow,
-                                   ws.qa[in], ws.qb[in], ws.qc[in], ws.hits, ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib);
+                                   ws.qa[in], ws.qb[in], ws.qc[in], hits_in, ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib, hits_out, back_in, back_out);
             else
-                hipLaunchKernelGGL(k_shade<false>, bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, cin, cout, overflow, ws.qa[in], ws.qb[in], ws.qc[in], ws.hits,
-                                   ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib, ws.work);
+                hipLaunchKernelGGL(k_shade<false>, bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, cin, cout, overflow, ws.qa[in], ws.qb[in], ws.qc[in], hits_in,
+                                   ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib, ws.work, hits_out, back_in, back_out);
         }
         HIP_TRY(hipGetLastError());
         if (use_events) HIP_TRY(hipEventRecord(s->ev1, st));
@@ -1313,7 +1453,7 @@ static int render_passes(RtScene* s, const Workspace& ws, const RtCamera* cam, c
         done += chunk;
         if (!h_folded) continue;
         const int rows = p->max_depth + 2;
-        hipLaunchKernelGGL(k_fold_counts, dim3((rows + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, ws.counts, rows, ws.folded);
+        hipLaunchKernelGGL(k_fold_counts, dim3((rows + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, ws.counts, back, rows, ws.folded);
         HIP_TRY(hipMemcpyAsync(h_folded, ws.folded, (size_t)rows * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (h_folded[0] != 0)
@@ -1344,7 +1484,11 @@ static int render_passes(RtScene* s, const Workspace& ws, const RtCamera* cam, c
     if (debug_work && h_folded) {   // developer output: wave-level counters of the instrumented k_trace
         unsigned long long w2[16];
         HIP_TRY(hipMemcpy(w2, ws.work + 16, sizeof(w2), hipMemcpyDeviceToHost));
+        std::fprintf(stderr, "rays whose closest hit the shading kernel settled: %llu\n", w2[12]);
         std::fprintf(stderr, "k_trace wave counters: outer %llu refills %llu node-iters %llu leaf-iters %llu\n", w2[0], w2[1], w2[2], w2[3]);
+        std::fprintf(stderr, "k_trace stack: deepest %llu of %d; node steps %llu, of which with more than 4 / 6 / 8 / 10 / 12 / 16 entries: %.4f %.4f %.4f %.4f %.5f %.6f\n", w2[4],
+                     s->plan.stack_cap, w2[5], (double)w2[6] / std::max(1ull, w2[5]), (double)w2[7] / std::max(1ull, w2[5]), (double)w2[8] / std::max(1ull, w2[5]),
+                     (double)w2[9] / std::max(1ull, w2[5]), (double)w2[10] / std::max(1ull, w2[5]), (double)w2[11] / std::max(1ull, w2[5]));
     }
     return RT_OK;
 }
@@ -1474,6 +1618,10 @@ static int scene_set(RtScene* s, int kind, const int32_t* ids, int32_t n, const 
     const std::vector<rt_f4>& host = kind == 0 ? s->flat.spheres : s->flat.mspheres;
     rt_f4* dev = const_cast<rt_f4*>(kind == 0 ? s->view.spheres : s->view.mspheres);
     const size_t per = kind == 0 ? 1 : 3;
+    if (s->has_local_media) {   // set_prims_host has emptied the media's lists of surfaces inside their boundaries
+        HIP_TRY(hipMemcpy(const_cast<rt_f4*>(s->view.media), s->flat.media.data(), s->flat.media.size() * sizeof(rt_f4), hipMemcpyHostToDevice));
+        s->has_local_media = false;
+    }
     if (touched.size() > 64) HIP_TRY(hipMemcpy(dev, host.data(), host.size() * sizeof(rt_f4), hipMemcpyHostToDevice));
     else for (int32_t rec : touched) HIP_TRY(hipMemcpy(dev + per * (size_t)rec, host.data() + per * (size_t)rec, per * sizeof(rt_f4), hipMemcpyHostToDevice));
     return RT_OK;
@@ -1773,11 +1921,11 @@ int rt_trace_primary(RtScene* s, const RtCamera* cam, const RtRenderParams* p, i
             if (s->shade_fused) {
                 dim3 lgrid((unsigned)std::max(RT_SHARDS, s->n_cu / RT_SHARDS / RT_SHARDS * RT_SHARDS), RT_SHARDS);
                 hipLaunchKernelGGL((k_shade_lds<true, true>), lgrid, dim3(1024), (size_t)s->shade_lds_bytes, 0, s->view, s->shade_plan, fr, 1, cap, cin,
-                                   ws.counts + 2 * row_words, ws.counts, ws.qa[0], ws.qb[0], ws.qc[0], ws.hits, ws.qa[1], ws.qb[1], ws.qc[1], ws.contrib);
+                                   ws.counts + 2 * row_words, ws.counts, ws.qa[0], ws.qb[0], ws.qc[0], ws.hits[1], ws.qa[1], ws.qb[1], ws.qc[1], ws.contrib, nullptr, nullptr, nullptr);
             } else
-                launch_trace(s, ws, false, 0, cap, cin, ws.counts + (size_t)(ws.rows + 1) * row_words, ws.qa[0], ws.qb[0]);
+                launch_trace(s, ws, false, 0, cap, cin, ws.counts + (size_t)(ws.rows + 1) * row_words, ws.qa[0], ws.qb[0], ws.hits[1]);
             dim3 fgrid((unsigned)std::max<size_t>(1, std::min<size_t>((n / RT_SHARDS + RT_BLOCK - 1) / RT_BLOCK + 1, 4096)), RT_SHARDS);
-            hipLaunchKernelGGL(k_primary_finish, fgrid, dim3(RT_BLOCK), 0, 0, s->view, fr, (uint32_t)sample, cap, cin, ws.qa[0], ws.qb[0], ws.hits, d_ids, d_t, d_n, d_fr,
+            hipLaunchKernelGGL(k_primary_finish, fgrid, dim3(RT_BLOCK), 0, 0, s->view, fr, (uint32_t)sample, cap, cin, ws.qa[0], ws.qb[0], ws.hits[1], d_ids, d_t, d_n, d_fr,
                                d_uv);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipDeviceSynchronize());

@@ -12,6 +12,7 @@ struct alignas(8) rt_i2 { int32_t x, y; };
 // ---- primitive kinds (also the top bits of a hit code)
 enum { RT_KIND_SPHERE = 0, RT_KIND_MSPHERE = 1, RT_KIND_RECT = 2, RT_KIND_BOX = 3, RT_KIND_MEDIUM = 4 };
 #define RT_HIT_NONE 0xFFFFFFFFu
+#define RT_SRC_RESOLVED 0xFFFFFFFEu   /* in a queued ray's source-primitive word: its closest surface hit is already in the hit stream */
 #define RT_HIT_CODE(kind, index) (((uint32_t)(kind) << 28) | (uint32_t)(index))
 #define RT_HIT_KIND(code) ((code) >> 28)
 #define RT_HIT_INDEX(code) ((code) & 0x0FFFFFFFu)
@@ -60,9 +61,11 @@ enum { RT_OP_TRANSLATE = 0, RT_OP_ROTATE_Y = 1 };
 //   m0 = (box.min xyz, -1/density)      m1 = (box.max xyz, material index as int)
 //   m2 = int (instance or -1, sphere first, sphere count, msphere first)
 //   m3 = int (msphere count, rect first, rect count, object id)
-//   m4 = int (box first, box count, 0, 0)
+//   m4 = int (box first, box count, local surface 0, local surface 1)
 //   m5 = int (fast kind: 0 = scan the ranges above, 1 = the boundary is the one sphere in m6, 2 = the one box in m6, m7;
-//             1 if m8, m9 hold the instance record of m2.x; 0; 0)
+//             1 if m8, m9 hold the instance record of m2.x; n | mask << 8: number of local surfaces 0..3 and, bit k, whether
+//             local surface k lies wholly inside the boundary; local surface 2)
+//   local surfaces: the only primitives (as one-primitive leaf codes) a ray can hit while inside the boundary, see flatten.cpp
 //   m6, m7 = that primitive's record, m8, m9 = that instance's record
 #define RT_MEDIUM_F4 10
 
