@@ -256,6 +256,14 @@ private:
     // near the boundary, or more than three candidates, leave the list empty and every ray goes through the tree.
     void emit_medium_locals(const std::vector<Item>& top) {
         if (index_of_obj.size() < b.objects.size()) index_of_obj.resize(b.objects.size(), -1);
+        // everything a ray can start or end on: the surfaces of the trees and the other media's boundaries
+        Box3 all;
+        for (const Item& it : top) all.grow(it.box);
+        std::vector<Box3> medium_box(media.size());
+        for (size_t mi = 0; mi < media.size(); ++mi) {
+            const rt_f4* rec = &out.media[mi * RT_MEDIUM_F4];
+            medium_box[mi].grow_pt(rec[0].x, rec[0].y, rec[0].z); medium_box[mi].grow_pt(rec[1].x, rec[1].y, rec[1].z);
+        }
         for (size_t mi = 0; mi < media.size(); ++mi) {
             rt_f4* rec = &out.media[mi * RT_MEDIUM_F4];
             int32_t fast, has_inst;
@@ -263,6 +271,19 @@ private:
             if (fast == 0 || has_inst) continue;
             const ObjNode& bo = b.objects[media[mi].boundary[0].obj];
             const Box3 bb = prim_box(bo);
+            if (fast == 1 && all.valid()) {
+                // A sphere boundary whose radius is at least twice the distance from its centre to the farthest corner of
+                // everything else: rays of the scene cross it far behind their origin and far beyond their end (rt_medium_collision).
+                Box3 rest = all;
+                for (size_t mj = 0; mj < media.size(); ++mj) if (mj != mi) rest.grow(medium_box[mj]);
+                double far2 = 0.0;
+                for (int c = 0; c < 8; ++c) {
+                    const double dx = ((c & 1) ? rest.mx[0] : rest.mn[0]) - bo.p[0], dy = ((c & 2) ? rest.mx[1] : rest.mn[1]) - bo.p[1],
+                                 dz = ((c & 4) ? rest.mx[2] : rest.mn[2]) - bo.p[2];
+                    far2 = std::max(far2, dx * dx + dy * dy + dz * dz);
+                }
+                if (std::fabs(bo.p[3]) >= 2.0 * std::sqrt(far2)) rec[5].y = i2f(has_inst | 2);
+            }
             const double size = std::fabs(bb.mx[0] - bb.mn[0]) + std::fabs(bb.mx[1] - bb.mn[1]) + std::fabs(bb.mx[2] - bb.mn[2]);
             const double pad = 1e-3 * (1.0 + size);
             // does the item's box come within `pad` of the boundary's solid?  (sphere boundary: distance from its centre to the box)

@@ -69,7 +69,12 @@ bool set_prims_host(FlatScene& f, const std::vector<int32_t> of_id[2], int kind,
     }
     // A moved primitive may enter or leave a medium's boundary: the lists of surfaces inside the boundaries (flatten.cpp,
     // emit_medium_locals) no longer hold, and every ray goes through the tree again.
-    for (size_t m = 0; m * RT_MEDIUM_F4 < f.media.size(); ++m) f.media[m * RT_MEDIUM_F4 + 5].z = 0.0f;   // count | mask << 8
+    for (size_t m = 0; m * RT_MEDIUM_F4 < f.media.size(); ++m) {
+        f.media[m * RT_MEDIUM_F4 + 5].z = 0.0f;   // count | mask << 8
+        int32_t flags; std::memcpy(&flags, &f.media[m * RT_MEDIUM_F4 + 5].y, 4);
+        flags &= 1;                               // ... nor the claim that a boundary encloses everything else
+        std::memcpy(&f.media[m * RT_MEDIUM_F4 + 5].y, &flags, 4);
+    }
     return true;
 }
 

@@ -934,8 +934,9 @@ static void launch_trace(RtScene* s, const Workspace& ws, bool stats, hipStream_
         else hipLaunchKernelGGL((k_trace<false, TB_, WIDE_, RES_, W4_, SP_>), grid, dim3(TB_), (size_t)s->lds_bytes, st, s->view, s->plan, cap,      \
                                 cin, cursors, qa, qb, hits, ws.work, s->stack_spill);                                         \
     } while (0)
-    if (s->plan.wide4 && s->plan.resident) RT_LAUNCH_TRACE(1024, true, true, true, false);
-    else if (s->plan.wide4 && spill) RT_LAUNCH_TRACE(1024, true, false, true, true);
+    // (a spilling stack first: with fewer entries in LDS a wide tree may have become resident, and only the general form spills)
+    if (s->plan.wide4 && spill) RT_LAUNCH_TRACE(1024, true, false, true, true);
+    else if (s->plan.wide4 && s->plan.resident) RT_LAUNCH_TRACE(1024, true, true, true, false);
     else if (s->plan.wide4) RT_LAUNCH_TRACE(1024, true, false, true, false);
     else if (s->trace_block == 1024 && s->plan.resident && spill) RT_LAUNCH_TRACE(1024, false, true, false, true);
     else if (s->trace_block == 1024 && s->plan.resident) RT_LAUNCH_TRACE(1024, false, true, false, false);
@@ -1021,8 +1022,8 @@ static int plan_trace(RtScene* s) {
         }
         const bool spill = s->plan.stack_total > s->plan.stack_cap;
         const void* fns[2];
-        if (s->plan.wide4 && s->plan.resident) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, true, true, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, true, true, false>); }
-        else if (s->plan.wide4 && spill) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, false, true, true>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, false, true, true>); }
+        if (s->plan.wide4 && spill) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, false, true, true>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, false, true, true>); }
+        else if (s->plan.wide4 && s->plan.resident) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, true, true, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, true, true, false>); }
         else if (s->plan.wide4) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, true, false, true, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, true, false, true, false>); }
         else if (s->plan.resident && spill) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, false, true, false, true>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, false, true, false, true>); }
         else if (s->plan.resident) { fns[0] = reinterpret_cast<const void*>(&k_trace<false, 1024, false, true, false, false>); fns[1] = reinterpret_cast<const void*>(&k_trace<true, 1024, false, true, false, false>); }
@@ -1308,6 +1309,10 @@ int rt_scene_create_ex(const RtBuilder* b, RtObj world, int device, int flags, R
             s->nodes_on_device = d_nodes;
         }
         rt::build_wide_bvh(f);
+        if (const char* e = std::getenv("RT_MEDIA_ENCLOSE")) {   // 0: ignore that a medium's boundary encloses the whole scene (A/B measurements)
+            if (std::atoi(e) == 0)
+                for (size_t m = 0; m * RT_MEDIUM_F4 < f.media.size(); ++m) { int32_t fl; std::memcpy(&fl, &f.media[m * RT_MEDIUM_F4 + 5].y, 4); fl &= 1; std::memcpy(&f.media[m * RT_MEDIUM_F4 + 5].y, &fl, 4); }
+        }
         RtSceneView v = f.view();
         int r;
         if ((r = upload(s, f.wnodes, &v.wnodes))) return r;
@@ -1618,7 +1623,7 @@ static int scene_set(RtScene* s, int kind, const int32_t* ids, int32_t n, const 
     const std::vector<rt_f4>& host = kind == 0 ? s->flat.spheres : s->flat.mspheres;
     rt_f4* dev = const_cast<rt_f4*>(kind == 0 ? s->view.spheres : s->view.mspheres);
     const size_t per = kind == 0 ? 1 : 3;
-    if (s->has_local_media) {   // set_prims_host has emptied the media's lists of surfaces inside their boundaries
+    if (!s->flat.media.empty()) {   // set_prims_host has withdrawn what the medium records said about the surfaces around their boundaries
         HIP_TRY(hipMemcpy(const_cast<rt_f4*>(s->view.media), s->flat.media.data(), s->flat.media.size() * sizeof(rt_f4), hipMemcpyHostToDevice));
         s->has_local_media = false;
     }

@@ -640,7 +640,7 @@ RT_HD bool rt_medium_span(const RtSceneView& sc, const MediaSrc& msrc, int m, v3
     v3 o = wo, d = wd;
     if (fast != 0) {
         // the boundary is one convex primitive: its two crossings are the entry and the exit (mediums.rs:46-47)
-        if (rt_uniform(f2i(m5.y)) != 0) {
+        if ((rt_uniform(f2i(m5.y)) & 1) != 0) {
             rt_f4 i0 = msrc.get(m, 8), i1 = msrc.get(m, 9);
             o = rt_to_object_point(i0, i1, wo); d = rt_to_object_dir(i0, wd);
         }
@@ -671,15 +671,23 @@ RT_HD bool rt_medium_span(const RtSceneView& sc, const MediaSrc& msrc, int m, v3
 
 // Free flight through medium m along the ray, limited by t_limit (the closest hit so far): the ray parameter of the
 // collision, or NaN when the ray does not collide in this medium.  `draw` = the medium's 32 random bits for this segment.
+// from_scene: the ray starts on a surface or inside a medium of the scene (every ray but a camera ray).
 template <class MediaSrc>
 RT_HD float rt_medium_collision(const RtSceneView& sc, const MediaSrc& msrc, int m, v3 wo, v3 wd, v3 winv, float len, float time, float tmin,
-                                float t_limit, uint32_t draw) {
+                                float t_limit, uint32_t draw, bool from_scene) {
     rt_f4 m0 = msrc.get(m, 0), m1 = msrc.get(m, 1);
-    if (!(rt_slab(m0.x, m0.y, m0.z, m1.x, m1.y, m1.z, wo, winv, tmin, t_limit) < rt_inf())) return rt_nan();
     float t1, t2;
-    if (!rt_medium_span(sc, msrc, m, wo, wd, time, t1, t2)) return rt_nan();
-    if (t1 < tmin) t1 = tmin;
-    if (t2 > t_limit) t2 = t_limit;
+    // A boundary that encloses the whole scene with room to spare (final_scene.yml's fog sphere of radius 5000 around a scene
+    // 1000 across; flagged by the flattener): a ray that starts in the scene and ends on something in the scene crosses the
+    // boundary behind its origin and beyond its end, so the clamps below would give t1 = tmin and t2 = t_limit whatever the
+    // crossings are -- they need not be computed.
+    if (from_scene && t_limit < rt_inf() && (rt_uniform(f2i(msrc.get(m, 5).y)) & 2) != 0) { t1 = tmin; t2 = t_limit; }
+    else {
+        if (!(rt_slab(m0.x, m0.y, m0.z, m1.x, m1.y, m1.z, wo, winv, tmin, t_limit) < rt_inf())) return rt_nan();
+        if (!rt_medium_span(sc, msrc, m, wo, wd, time, t1, t2)) return rt_nan();
+        if (t1 < tmin) t1 = tmin;
+        if (t2 > t_limit) t2 = t_limit;
+    }
     if (t1 >= t2) return rt_nan();
     if (t1 < 0.0f) t1 = 0.0f;
     float inside = (t2 - t1) * len;
@@ -703,7 +711,7 @@ RT_HD void rt_media_hits(const RtSceneView& sc, const MediaSrc& msrc, v3 wo, v3 
         }
         int lane4 = k & 3;
         uint32_t draw = lane4 == 0 ? r0 : (lane4 == 1 ? r1 : (lane4 == 2 ? r2 : r3));
-        float t = rt_medium_collision(sc, msrc, m, wo, wd, winv, len, time, tmin, hit.t, draw);
+        float t = rt_medium_collision(sc, msrc, m, wo, wd, winv, len, time, tmin, hit.t, draw, bounce > 1u);
         if (t < hit.t) { hit.t = t; hit.code = RT_HIT_CODE(RT_KIND_MEDIUM, (uint32_t)m); hit.inst = -1; }   // false for NaN
     }
 }

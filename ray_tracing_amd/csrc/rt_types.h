@@ -63,7 +63,8 @@ enum { RT_OP_TRANSLATE = 0, RT_OP_ROTATE_Y = 1 };
 //   m3 = int (msphere count, rect first, rect count, object id)
 //   m4 = int (box first, box count, local surface 0, local surface 1)
 //   m5 = int (fast kind: 0 = scan the ranges above, 1 = the boundary is the one sphere in m6, 2 = the one box in m6, m7;
-//             1 if m8, m9 hold the instance record of m2.x; n | mask << 8: number of local surfaces 0..3 and, bit k, whether
+//             bit 0: m8, m9 hold the instance record of m2.x, bit 1: the boundary encloses the whole scene with room to spare
+//             (flatten.cpp, emit_medium_locals); n | mask << 8: number of local surfaces 0..3 and, bit k, whether
 //             local surface k lies wholly inside the boundary; local surface 2)
 //   local surfaces: the only primitives (as one-primitive leaf codes) a ray can hit while inside the boundary, see flatten.cpp
 //   m6, m7 = that primitive's record, m8, m9 = that instance's record

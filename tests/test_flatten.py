@@ -374,3 +374,47 @@ def test_refit_refuses_what_it_cannot_move():
     flat.set_spheres([last], [[2, 0, -5, 0.5]])
     assert not np.array_equal(arrays(flat)["spheres"], before)
     flat.refit()
+
+
+def _medium_locals(flat):
+    a = arrays(flat)
+    med = a["media"].reshape(-1, 10, 4).view(np.int32)
+    return [(int(m[5, 2]) & 255, int(m[5, 2]) >> 8, [int(m[4, 2]), int(m[4, 3]), int(m[5, 3])]) for m in med]
+
+
+def test_media_list_the_surfaces_inside_their_boundary():
+    """flatten.cpp, emit_medium_locals: final_scene.yml's glass ball holds a dense medium (src/main.rs:392-405); the only surfaces
+    inside that boundary are the ball itself (wholly inside: flagged) and whichever ground boxes are tall enough to poke into it.
+    The fog that encloses the whole scene, media behind Translate / RotateY (cornell.yml) and boundaries near an instance list nothing."""
+    cfg, cam, b, world, _ = __import__("helpers").scene_pair("final_scene.yml")
+    for flags in (0, rt.RT_BVH_LINEAR):
+        loc = _medium_locals(FlatScene(b, world, flags))
+        n, mask, codes = loc[0]
+        assert 1 <= n <= 3 and mask != 0 and loc[1][0] == 0, loc
+        flagged = [codes[k] for k in range(n) if mask >> k & 1]
+        assert len(flagged) == 1 and (~flagged[0] >> 28) & 3 == 0          # one flagged entry, a sphere: the glass ball
+        a = arrays(FlatScene(b, world, flags))
+        ball = a["spheres"][~flagged[0] & 0x03FFFFFF]
+        assert np.allclose(ball, [360, 150, 145, 70])
+    cfg, cam, b, world, _ = __import__("helpers").scene_pair("cornell.yml")
+    assert all(n == 0 for n, _, _ in _medium_locals(FlatScene(b, world)))
+    # hand-built: a list of up to three, none beyond; an instance that reaches into the boundary forbids the list
+    def ball_scene(n_inside, with_instance):
+        bb = rt.Builder()
+        m = bb.lambertian((0.5, 0.5, 0.5))
+        kids = [bb.constant_medium_from_color(bb.sphere((0, 0, 0), 5.0, m), 0.3, (1, 1, 1))]
+        kids += [bb.sphere((0.5 * i - 1.0, 0, 0), 0.2, m) for i in range(n_inside)]
+        kids.append(bb.sphere((20, 0, 0), 1.0, m))                          # far away: never in a list
+        if with_instance:
+            kids.append(bb.translate(bb.sphere((0, 0, 0), 0.5, m), (1.0, 1.0, 1.0)))
+        return bb, bb.list(kids)
+    for n_inside, with_instance, want in ((1, False, 1), (3, False, 3), (4, False, 0), (2, True, 0), (0, False, 0)):
+        bb, w = ball_scene(n_inside, with_instance)
+        n, mask, _ = _medium_locals(FlatScene(bb, w))[0]
+        assert n == want and (mask == (1 << want) - 1), (n_inside, with_instance, n, mask)
+    # moving any sphere empties the lists
+    bb, w = ball_scene(2, False)
+    flat = FlatScene(bb, w)
+    assert _medium_locals(flat)[0][0] == 2
+    flat.set_spheres([bb.object_count() - 1], [[1, 1, 1, 0.5]])
+    assert _medium_locals(flat)[0][0] == 0

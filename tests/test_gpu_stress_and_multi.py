@@ -422,3 +422,69 @@ def test_three_ranks_shard_the_hip_renderer(gpu_required, tmp_path):
     want, _, _ = scene.render(cam, rt.render_params(96, 96, 7, cfg.max_depth, RENDER_SEED))
     assert want.sum() > 0 and np.allclose(got, want, rtol=2e-6, atol=1e-6)
     scene.close()
+
+
+def _walk_scene(b, extra_inside=True, poke=True, move=None):
+    """A glass ball with a dense medium inside it (as src/main.rs:392-405 builds one), a small metal sphere wholly inside the
+    ball, a box that pokes into it, a light and a floor: rays that scatter inside the ball can only meet the ball's own surface,
+    the small sphere or the box before they leave it.  Returns (world, id of a free sphere outside the ball)."""
+    glass = b.dielectric(1.5)
+    kids = [b.sphere((0, 0, -10), 3.0, glass)]
+    kids.append(b.constant_medium_from_color(b.sphere((0, 0, -10), 3.0, glass), 0.9, (0.3, 0.5, 0.9)))
+    if extra_inside:
+        kids.append(b.sphere((0.6, 0.4, -10.2), 0.7, b.metal((0.9, 0.8, 0.7), 0.1)))
+    if poke:
+        kids.append(b.box((-1.0, -6.0, -11.0), (1.0, -2.2, -9.0), b.lambertian((0.7, 0.3, 0.3))))
+    free_id = b.object_count()
+    kids.append(b.sphere(move if move is not None else (7.0, 0.0, -10.0), 1.0, b.lambertian((0.2, 0.7, 0.3))))
+    kids.append(b.rectangle(b.diffuse_light_from_color((6, 6, 6)), -4, 4, -14, -6, 8.0, rt.RECT_XZ))
+    kids.append(b.rectangle(b.lambertian((0.6, 0.6, 0.6)), -30, 30, -40, 10, -6.0, rt.RECT_XZ))
+    return b.list(kids), free_id
+
+
+def test_walks_inside_a_medium_skip_the_tree_search_exactly(gpu_required):
+    """Rays that leave a collision inside the ball are settled by the shading kernel against the surfaces listed in the medium
+    record (three here: the ball, the sphere inside it, the box that pokes in) and never reach the closest-hit kernel.  The image
+    and the ray counts must be those of the render that sends every ray through the tree, and of the oracle; and a sphere moved
+    into the ball empties the list (the scene then equals one built from the moved spheres)."""
+    cam = rt.make_camera((0, 2, 6), (0, 0, -10), (0, 1, 0), 35.0, 1.5, 0.05, 16.0)
+    W, H, spp = 240, 160, 8
+    p = rt.render_params(W, H, spp, 50, RENDER_SEED, background=(0.05, 0.06, 0.08))
+
+    def render(local, **kw):
+        b = rt.Builder()
+        world, free_id = _walk_scene(b, **kw)
+        os.environ["RT_LOCAL_MEDIA"] = local
+        os.environ["RT_DEBUG_WORK"] = "1"
+        try:
+            scene = rt.Scene(b, world, 0)
+            img, _, st = scene.render(cam, p)
+            _, _, counted = scene.render(cam, rt.render_params(W, H, 1, 50, RENDER_SEED, flags=rt.RT_FLAG_COUNTERS))     # the instrumented kernels take the same route
+        finally:
+            os.environ.pop("RT_LOCAL_MEDIA", None); os.environ.pop("RT_DEBUG_WORK", None)
+        return scene, img, st, free_id
+    for kw in (dict(), dict(extra_inside=False), dict(poke=False), dict(extra_inside=False, poke=False)):
+        s1, on, st_on, _ = render("1", **kw)
+        s0, off, st_off, _ = render("0", **kw)
+        assert st_on.rays == st_off.rays and list(st_on.rays_per_bounce) == list(st_off.rays_per_bounce) and np.array_equal(on, off), kw
+        assert st_on.rays > 3 * W * H * spp                              # the walks are there: paths are long
+        s0.close(); s1.close()
+    ob = OracleBuilder()
+    ow, _ = _walk_scene(ob)
+    ob.set_world(ow)
+    oa, _, ost = oracle_render(ob, OracleCamera(cam), W, H, spp, 50, RENDER_SEED, background=(0.05, 0.06, 0.08))
+    scene, img, st, free_id = render("1")
+    same = np.mean(np.all(np.abs(img - oa) <= 1e-3 * (spp + np.abs(oa)), axis=2))
+    assert same >= 0.97 and abs(int(st.rays) - ost["rays"]) <= 3e-3 * ost["rays"], (same, st.rays, ost["rays"])
+    # a fourth surface inside the ball: the list no longer describes it, and a moved primitive must empty it
+    scene.set_spheres([free_id], [[-0.8, -0.5, -9.5, 1.0]])
+    scene.refit()
+    moved, _, st_m = scene.render(cam, p)
+    b2 = rt.Builder()
+    w2, _ = _walk_scene(b2, move=(-0.8, -0.5, -9.5))
+    fresh = rt.Scene(b2, w2, 0)
+    want, _, st_w = fresh.render(cam, p)
+    got_fix = fresh.trace_primary(cam, p, 0)
+    assert st_m.rays == st_w.rays and np.array_equal(moved, want) and not np.array_equal(moved, img)
+    assert (got_fix["id"] >= 0).any()
+    scene.close(); fresh.close()
