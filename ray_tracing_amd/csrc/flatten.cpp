@@ -250,10 +250,11 @@ private:
     // boundary; the reference then searches the whole world again, src/lib.rs:63).  For a medium whose boundary is one sphere or
     // one box in world space, every surface point inside the boundary belongs to a primitive that meets the boundary's solid:
     // when those are at most three world-space primitives, the medium record lists them (as one-primitive leaf codes in m4.z,
-    // m4.w, m5.w; m5.z = count | mask << 8, bit k of the mask: entry k lies wholly inside the boundary).  A ray that starts
-    // inside the boundary and hits a flagged primitive has found its closest surface hit -- anything nearer would lie inside
-    // the boundary too and be in the list -- so the shading kernel can settle that ray's closest-hit search itself.  An instance
-    // near the boundary, or more than three candidates, leave the list empty and every ray goes through the tree.
+    // m4.w, m5.w, those that lie wholly inside the boundary first; m5.z = count | mask << 8, bit k of the mask: entry k lies
+    // wholly inside).  A ray that starts inside the boundary and hits a flagged primitive anywhere has found its closest surface
+    // hit among the list's entries: the segment up to that hit lies inside the (convex) boundary, so whatever it meets first is
+    // inside the boundary too and is in the list -- the shading kernel can settle that ray's closest-hit search itself.  An
+    // instance near the boundary, or more than three candidates, leave the list empty and every ray goes through the tree.
     void emit_medium_locals(const std::vector<Item>& top) {
         if (index_of_obj.size() < b.objects.size()) index_of_obj.resize(b.objects.size(), -1);
         // everything a ray can start or end on: the surfaces of the trees and the other media's boundaries
@@ -323,8 +324,12 @@ private:
                 ++n;
             }
             if (!ok || n == 0 || mask == 0) continue;
-            rec[4].z = i2f(codes[0]); rec[4].w = i2f(codes[1]); rec[5].w = i2f(codes[2]);
-            rec[5].z = i2f(n | (mask << 8));
+            // flagged entries first: the kernel learns whether any of them is hit before an unflagged, nearer hit can hide it
+            int ordered[3] = {0, 0, 0}, k = 0, n_flagged = 0;
+            for (int pass = 0; pass < 2; ++pass)
+                for (int i = 0; i < n; ++i) if (((mask >> i) & 1) == (pass == 0 ? 1 : 0)) { ordered[k++] = codes[i]; if (pass == 0) ++n_flagged; }
+            rec[4].z = i2f(ordered[0]); rec[4].w = i2f(ordered[1]); rec[5].w = i2f(ordered[2]);
+            rec[5].z = i2f(n | (((1 << n_flagged) - 1) << 8));
         }
     }
     int emit_instance(int chain, int root) {

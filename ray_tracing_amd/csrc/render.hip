@@ -339,6 +339,10 @@ struct ShadeMedia {   // medium records: the first RT_SHADE_MEDIA_LDS media from
 // contribution slot; out.alive = the path continues with the ray out.na / nb / nc.  out.postponed = the hit needs a costly
 // texture and `may_postpone` was set: nothing has been written for the ray then.
 // Tab: see RtGlobalTables; MediaSrc: see rt_media_hits.  STATS = true also counts shades per material kind into `work`.
+// The surfaces that lie wholly inside the boundary of a medium that lists its local surfaces (flatten.cpp, emit_medium_locals), over
+// all media, at most four: a ray that starts ON one of them is inside that boundary as much as one that starts at a collision in
+// the medium.  code / mask: the surface's hit code and the bits that identify it (a box's side index is masked out).
+struct RtLocalSurfs { int32_t enabled, n; uint32_t code[4], mask[4]; int32_t medium[4]; };
 struct ShadeOut { bool alive, postponed, resolved; int cls; rt_f4 na, nb, nc, nh; };   // resolved: nh is the scattered ray's closest surface hit
 // Classes of hits that a wave may set aside and shade together later (k_shade_lds): 0 = the material's texture tree holds a
 // Noise (Perlin turbulence, ~1300 instructions).  RT_POSTPONE_CLASSES = 2 adds dielectrics, 3 also metals (measured: not worth
@@ -348,7 +352,7 @@ struct ShadeOut { bool alive, postponed, resolved; int cls; rt_f4 na, nb, nc, nh
 #endif
 template <bool STATS, class Tab, class MediaSrc>
 __device__ __forceinline__ void shade_ray(const RtSceneView& sc, const Tab& tab, const MediaSrc& msrc, const RtFrameDev& fr, int bounce,
-                                          rt_f4 a, rt_f4 b, rt_f4 c, rt_f4 h, bool may_postpone, bool local_ok, rt_f4* contrib,
+                                          rt_f4 a, rt_f4 b, rt_f4 c, rt_f4 h, bool may_postpone, const RtLocalSurfs& ls, rt_f4* contrib,
                                           unsigned long long* work, ShadeOut& out) {
     v3 o = mk3(a.x, a.y, a.z), d = mk3(b.x, b.y, b.z), beta = mk3(c.x, c.y, c.z);
     float time = a.w;
@@ -397,31 +401,40 @@ __device__ __forceinline__ void shade_ray(const RtSceneView& sc, const Tab& tab,
                 out.nb.x = dir.x; out.nb.y = dir.y; out.nb.z = dir.z;
                 out.nb.w = i2f(RT_HIT_KIND(hit.code) == RT_KIND_MEDIUM ? (int)RT_HIT_NONE : (int)hit.code);
                 out.nc.x = beta.x; out.nc.y = beta.y; out.nc.z = beta.z; out.nc.w = c.w;
-                // A ray that leaves a collision inside a medium whose boundary encloses a known handful of surfaces (flatten.cpp,
-                // emit_medium_locals): if it hits one that lies wholly inside the boundary, that is its closest surface hit --
-                // the same test with the same operands as the tree search would make, so the same record -- and the closest-hit
-                // kernel skips the ray.  (final_scene.yml: a third of all rays are such steps of walks inside the glass ball.)
-                if (local_ok && RT_HIT_KIND(hit.code) == RT_KIND_MEDIUM) {
-                    const int m = (int)RT_HIT_INDEX(hit.code);
-                    const rt_f4 m5 = msrc.get(m, 5);
-                    const int n_local = f2i(m5.z) & 255, inside_mask = f2i(m5.z) >> 8;
+                // A ray that starts inside the boundary of a medium which encloses a known handful of surfaces (flatten.cpp,
+                // emit_medium_locals; those that lie wholly inside the boundary come first in the list) -- at a collision in the
+                // medium, or on one of those wholly-inside surfaces: if it hits one of these anywhere, everything up to that hit
+                // is inside the boundary, so the nearest hit among the list's entries is its closest surface hit -- found by the
+                // same tests with the same operands as the tree search would make, so the same record -- and the closest-hit
+                // kernel never sees the ray.  (final_scene.yml: a third of all rays are such steps of walks inside the glass ball.)
+                if (ls.enabled) {
+                    int m = -1;
+                    uint32_t from = RT_HIT_NONE;                       // the surface the ray starts on, as the tree search is told (k_trace's src)
+                    if (RT_HIT_KIND(hit.code) == RT_KIND_MEDIUM) m = (int)RT_HIT_INDEX(hit.code);
+                    else if (hit.inst < 0) {
+                        for (int k = 0; k < ls.n; ++k) if ((hit.code & ls.mask[k]) == ls.code[k]) m = ls.medium[k];
+                        from = hit.code;
+                    }
+                    const rt_f4 m5 = msrc.get(max(m, 0), 5);
+                    const int n_local = m >= 0 ? (f2i(m5.z) & 255) : 0, inside_mask = f2i(m5.z) >> 8;
                     if (n_local > 0) {
                         const rt_f4 m4 = msrc.get(m, 4);
                         RtTrav lt; rt_trav_ray(lt, sf.p, dir); lt.inst = -1; lt.sp = 0; lt.cur = RT_EMPTY_STACK;
                         RtHit nh; nh.t = rt_inf(); nh.code = RT_HIT_NONE; nh.inst = -1;
-                        rt_leaf_test<false>(tab, f2i(m4.z), time, RT_TMIN, RT_HIT_NONE, lt, nh, nullptr);
-                        int which = nh.code != RT_HIT_NONE ? 1 : 0;
+                        rt_leaf_test<false>(tab, f2i(m4.z), time, RT_TMIN, from, lt, nh, nullptr);
+                        bool inside_hit = nh.code != RT_HIT_NONE;          // entry 0 is always a flagged one
                         if (n_local > 1) {
                             const float t0 = nh.t;
-                            rt_leaf_test<false>(tab, f2i(m4.w), time, RT_TMIN, RT_HIT_NONE, lt, nh, nullptr);
-                            if (nh.t < t0) which = 2;
+                            rt_leaf_test<false>(tab, f2i(m4.w), time, RT_TMIN, from, lt, nh, nullptr);
+                            // a flagged entry tested after a hit on another flagged one need not be hit itself: one is enough
+                            if ((inside_mask & 2) && nh.t < t0) inside_hit = true;
                         }
                         if (n_local > 2) {
                             const float t0 = nh.t;
-                            rt_leaf_test<false>(tab, f2i(m5.w), time, RT_TMIN, RT_HIT_NONE, lt, nh, nullptr);
-                            if (nh.t < t0) which = 4;
+                            rt_leaf_test<false>(tab, f2i(m5.w), time, RT_TMIN, from, lt, nh, nullptr);
+                            if ((inside_mask & 4) && nh.t < t0) inside_hit = true;
                         }
-                        if (which & inside_mask) {
+                        if (inside_hit) {
                             out.resolved = true;
                             out.nh.x = nh.t; out.nh.y = i2f((int)nh.code); out.nh.z = i2f(-1); out.nh.w = 0.0f;
                             out.nb.w = i2f((int)RT_SRC_RESOLVED);
@@ -496,7 +509,7 @@ template <bool STATS>
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev fr, int bounce, uint32_t cap, const uint32_t* counts_in,
                                                     uint32_t* counts_out, uint32_t* overflow, const rt_f4* ia, const rt_f4* ib, const rt_f4* ic,
                                                     const rt_f4* hits, rt_f4* oa, rt_f4* ob, rt_f4* oc, rt_f4* contrib,
-                                                    unsigned long long* work, rt_f4* hits_out, const uint32_t* back_in, uint32_t* back_out) {
+                                                    unsigned long long* work, rt_f4* hits_out, const uint32_t* back_in, uint32_t* back_out, RtLocalSurfs ls) {
     const uint32_t n_front = min(counts_in[blockIdx.y * RT_COUNT_STRIDE], cap);
     const uint32_t n = n_front + region_back_count(back_in, blockIdx.y, n_front, cap, overflow);
     if (blockIdx.x * RT_BLOCK >= n) return;
@@ -510,14 +523,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(RtSceneView sc, RtFrameDev f
     uint32_t* n_out_ptr = counts_out + out_shard * RT_COUNT_STRIDE;
     ia += (size_t)blockIdx.y * cap; ib += (size_t)blockIdx.y * cap; ic += (size_t)blockIdx.y * cap; hits += (size_t)blockIdx.y * cap;
     oa += (size_t)out_shard * cap; ob += (size_t)out_shard * cap; oc += (size_t)out_shard * cap;
-    const bool local_ok = hits_out != nullptr && back_out != nullptr;     // the next bounce's hit stream and back counters, for rays whose closest hit is settled here
-    uint32_t* n_back_ptr = local_ok ? back_out + out_shard * RT_COUNT_STRIDE : nullptr;
-    if (local_ok) hits_out += (size_t)out_shard * cap;
+    if (!(hits_out != nullptr && back_out != nullptr)) ls.enabled = 0;    // the next bounce's hit stream and back counters, for rays whose closest hit is settled here
+    uint32_t* n_back_ptr = ls.enabled ? back_out + out_shard * RT_COUNT_STRIDE : nullptr;
+    if (ls.enabled) hits_out += (size_t)out_shard * cap;
 
     // Returns true when the hit was postponed.  Called from wave-uniform control flow only (the append votes over the wave).
     auto shade = [&](uint32_t i, bool valid, bool may_postpone) -> bool {
         ShadeOut out; shade_out_clear(out);
-        if (valid) shade_ray<STATS>(sc, tab, msrc, fr, bounce, ld4(ia + i), ld4(ib + i), bounce == 1 ? rt_first_c(blockIdx.y, i) : ld4(ic + i), ld4(hits + i), may_postpone, local_ok, contrib, work, out);
+        if (valid) shade_ray<STATS>(sc, tab, msrc, fr, bounce, ld4(ia + i), ld4(ib + i), bounce == 1 ? rt_first_c(blockIdx.y, i) : ld4(ic + i), ld4(hits + i), may_postpone, ls, contrib, work, out);
         shade_append(out, n_out_ptr, n_back_ptr, overflow, cap, oa, ob, oc, hits_out);
         return out.postponed;
     };
@@ -627,7 +640,7 @@ template <bool FUSED, bool PROBE = false>
 __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan pl, RtFrameDev fr, int bounce, uint32_t cap, const uint32_t* counts_in,
                                                     uint32_t* counts_out, uint32_t* overflow, const rt_f4* ia, const rt_f4* ib, const rt_f4* ic,
                                                     const rt_f4* hits, rt_f4* oa, rt_f4* ob, rt_f4* oc, rt_f4* contrib, rt_f4* hits_out,
-                                                    const uint32_t* back_in, uint32_t* back_out) {
+                                                    const uint32_t* back_in, uint32_t* back_out, RtLocalSurfs ls) {
     const uint32_t n_front = min(counts_in[blockIdx.y * RT_COUNT_STRIDE], cap);
     const uint32_t n = n_front + region_back_count(back_in, blockIdx.y, n_front, cap, overflow);
     if (blockIdx.x * 1024u >= n) return;
@@ -658,9 +671,9 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
     uint32_t* n_out_ptr = counts_out + out_shard * RT_COUNT_STRIDE;
     ia += (size_t)blockIdx.y * cap; ib += (size_t)blockIdx.y * cap; ic += (size_t)blockIdx.y * cap; hits += (size_t)blockIdx.y * cap;
     oa += (size_t)out_shard * cap; ob += (size_t)out_shard * cap; oc += (size_t)out_shard * cap;
-    const bool local_ok = !FUSED && hits_out != nullptr && back_out != nullptr;
-    uint32_t* n_back_ptr = local_ok ? back_out + out_shard * RT_COUNT_STRIDE : nullptr;
-    if (local_ok) hits_out += (size_t)out_shard * cap;
+    if (FUSED || !(hits_out != nullptr && back_out != nullptr)) ls.enabled = 0;
+    uint32_t* n_back_ptr = ls.enabled ? back_out + out_shard * RT_COUNT_STRIDE : nullptr;
+    if (ls.enabled) hits_out += (size_t)out_shard * cap;
 
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     lds_f4* stage = tab.lds + pl.off_stage + wave * 256u;
@@ -725,7 +738,7 @@ __global__ __launch_bounds__(1024) void k_shade_lds(RtSceneView sc, RtShadePlan 
         if (valid) {
             if (FUSED) h = closest(a, b);
             if (FUSED && PROBE) *reinterpret_cast<float4*>(const_cast<rt_f4*>(hits) + i) = make_float4(h.x, h.y, h.z, h.w);
-            shade_ray<false>(sc, tab, tab, fr, bounce, a, b, c, h, may_post, local_ok, contrib, nullptr, out);
+            shade_ray<false>(sc, tab, tab, fr, bounce, a, b, c, h, may_post, ls, contrib, nullptr, out);
         }
         if (shade_append(out, n_out_ptr, n_back_ptr, overflow, cap, oa, ob, oc, hits_out)) landed = true;
         if (may_post) {
@@ -905,6 +918,7 @@ struct RtScene {
     double bvh_build_seconds = 0.0;        // device time of that build
     int top_first = 0;                     // first node of the region k_trace should keep in LDS (see plan_trace)
     int trace_block = 1024;                // threads per k_trace block (1024, or 256 where a block cannot have 160 KB of LDS)
+    RtLocalSurfs local_surfs;              // ... and the wholly-inside surfaces of those lists (kernel argument of the shading kernels)
     bool has_local_media = false;          // some medium record lists the surfaces inside its boundary (flatten.cpp, emit_medium_locals)
     void* stack_spill = nullptr;           // k_trace: global part of the traversal stacks (entries beyond plan.stack_cap), [entry][thread of the grid]
     bool shade_lds = false;                // the shading tables fit one CU's LDS: k_shade_lds instead of k_shade
@@ -1335,7 +1349,23 @@ int rt_scene_create_ex(const RtBuilder* b, RtObj world, int device, int flags, R
         if ((r = upload(s, f.perlin_perm, &v.perlin_perm))) return r;
         if ((r = upload(s, f.boxes, &v.boxes))) return r;
         s->view = v;
-        for (size_t m = 0; m * RT_MEDIUM_F4 < f.media.size(); ++m) { int32_t nl; std::memcpy(&nl, &f.media[m * RT_MEDIUM_F4 + 5].z, 4); if ((nl & 255) > 0) s->has_local_media = true; }
+        std::memset(&s->local_surfs, 0, sizeof(s->local_surfs));
+        for (size_t m = 0; m * RT_MEDIUM_F4 < f.media.size(); ++m) {
+            int32_t nl, codes[3];
+            std::memcpy(&nl, &f.media[m * RT_MEDIUM_F4 + 5].z, 4);
+            std::memcpy(&codes[0], &f.media[m * RT_MEDIUM_F4 + 4].z, 4); std::memcpy(&codes[1], &f.media[m * RT_MEDIUM_F4 + 4].w, 4); std::memcpy(&codes[2], &f.media[m * RT_MEDIUM_F4 + 5].w, 4);
+            if ((nl & 255) == 0) continue;
+            s->has_local_media = true; s->local_surfs.enabled = 1;
+            for (int k = 0; k < (nl & 255); ++k) {
+                if (!((nl >> 8) >> k & 1) || s->local_surfs.n >= 4) continue;
+                const uint32_t x = ~(uint32_t)codes[k], kind = (x >> 28) & 3u, idx = x & 0x03FFFFFFu;
+                RtLocalSurfs& l = s->local_surfs;
+                l.code[l.n] = kind == RT_KIND_BOX ? RT_HIT_CODE(kind, idx << 3) : RT_HIT_CODE(kind, idx);
+                l.mask[l.n] = kind == RT_KIND_BOX ? ~7u : ~0u;
+                l.medium[l.n] = (int32_t)m;
+                l.n++;
+            }
+        }
         if ((r = plan_trace(s))) return r;
         if ((r = plan_shade(s))) return r;
         return RT_OK;
@@ -1404,6 +1434,12 @@ static int render_passes(RtScene* s, const Workspace& ws, const RtCamera* cam, c
     const char* env_local = std::getenv("RT_LOCAL_MEDIA");
     const bool local_media = s->has_local_media && !(env_local && std::atoi(env_local) == 0) && ws.hits[1] && !(s->shade_fused && !instrumented);
     uint32_t* back = local_media ? ws.counts + (size_t)2 * ws.rows * row_words : nullptr;   // sizes of the regions' back parts, [bounce][region]
+    RtLocalSurfs ls = s->local_surfs;
+    if (!local_media) ls.enabled = 0;
+    // Rays that start ON a wholly-inside surface (a reflection off the inner side of final_scene.yml's glass ball) can be settled the
+    // same way; measured, it moves 1.4 ms per step from k_trace to the shading kernel and gains nothing, so it is off unless
+    // RT_LOCAL_SURFACES=1: only rays that leave a collision in a medium are settled.
+    { const char* e = std::getenv("RT_LOCAL_SURFACES"); if (!(e && std::atoi(e) != 0)) ls.n = 0; }
     if (instrumented || debug_work) HIP_TRY(hipMemsetAsync(ws.work, 0, 32 * sizeof(unsigned long long), st));
 
     for (int done = 0; done < p->spp;) {
@@ -1438,16 +1474,16 @@ static int render_passes(RtScene* s, const Workspace& ws, const RtCamera* cam, c
             if (time_trace) HIP_TRY(hipEventRecord(s->ev_trace[2 * (b - 1) + 1], st));
             if (instrumented)
                 hipLaunchKernelGGL(k_shade<true>, bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, cin, cout, overflow, ws.qa[in], ws.qb[in], ws.qc[in], hits_in,
-                                   ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib, ws.work, hits_out, back_in, back_out);
+                                   ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib, ws.work, hits_out, back_in, back_out, ls);
             else if (fused)
                 hipLaunchKernelGGL(k_shade_lds<true>, lgrid, dim3(1024), (size_t)s->shade_lds_bytes, st, s->view, s->shade_plan, fr, b, cap, cin, cout, overflow,
-                                   ws.qa[in], ws.qb[in], ws.qc[in], hits_in, ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib, hits_out, back_in, back_out);
+                                   ws.qa[in], ws.qb[in], ws.qc[in], hits_in, ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib, hits_out, back_in, back_out, ls);
             else if (s->shade_lds)
                 hipLaunchKernelGGL(k_shade_lds<false>, lgrid, dim3(1024), (size_t)s->shade_lds_bytes, st, s->view, s->shade_plan, fr, b, cap, cin, cout, overflow,
-                                   ws.qa[in], ws.qb[in], ws.qc[in], hits_in, ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib, hits_out, back_in, back_out);
+                                   ws.qa[in], ws.qb[in], ws.qc[in], hits_in, ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib, hits_out, back_in, back_out, ls);
             else
                 hipLaunchKernelGGL(k_shade<false>, bgrid, dim3(RT_BLOCK), 0, st, s->view, fr, b, cap, cin, cout, overflow, ws.qa[in], ws.qb[in], ws.qc[in], hits_in,
-                                   ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib, ws.work, hits_out, back_in, back_out);
+                                   ws.qa[outq], ws.qb[outq], ws.qc[outq], ws.contrib, ws.work, hits_out, back_in, back_out, ls);
         }
         HIP_TRY(hipGetLastError());
         if (use_events) HIP_TRY(hipEventRecord(s->ev1, st));
@@ -1461,6 +1497,15 @@ static int render_passes(RtScene* s, const Workspace& ws, const RtCamera* cam, c
         hipLaunchKernelGGL(k_fold_counts, dim3((rows + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, ws.counts, back, rows, ws.folded);
         HIP_TRY(hipMemcpyAsync(h_folded, ws.folded, (size_t)rows * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (back && std::getenv("RT_DEBUG_COUNTS")) {   // developer output: per bounce, the rays in the front and in the back parts of the regions
+            std::vector<uint32_t> hc((size_t)3 * ws.rows * row_words);
+            HIP_TRY(hipMemcpy(hc.data(), ws.counts, hc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            for (int b = 1; b <= p->max_depth; ++b) {
+                unsigned long long f = 0, k = 0;
+                for (int sh = 0; sh < RT_SHARDS; ++sh) { f += hc[((size_t)b * RT_SHARDS + sh) * RT_COUNT_STRIDE]; k += hc[((size_t)(2 * ws.rows + b) * RT_SHARDS + sh) * RT_COUNT_STRIDE]; }
+                std::fprintf(stderr, "bounce %2d: front %10llu  back %10llu\n", b, f, k);
+            }
+        }
         if (h_folded[0] != 0)
             return rt_set_error(RT_ERR_INTERNAL, "ray queue overflow: " + std::to_string(h_folded[0]) + " rays did not fit their queue region (the image is incomplete)");
         if (use_events) {
@@ -1625,7 +1670,7 @@ static int scene_set(RtScene* s, int kind, const int32_t* ids, int32_t n, const 
     const size_t per = kind == 0 ? 1 : 3;
     if (!s->flat.media.empty()) {   // set_prims_host has withdrawn what the medium records said about the surfaces around their boundaries
         HIP_TRY(hipMemcpy(const_cast<rt_f4*>(s->view.media), s->flat.media.data(), s->flat.media.size() * sizeof(rt_f4), hipMemcpyHostToDevice));
-        s->has_local_media = false;
+        s->has_local_media = false; std::memset(&s->local_surfs, 0, sizeof(s->local_surfs));
     }
     if (touched.size() > 64) HIP_TRY(hipMemcpy(dev, host.data(), host.size() * sizeof(rt_f4), hipMemcpyHostToDevice));
     else for (int32_t rec : touched) HIP_TRY(hipMemcpy(dev + per * (size_t)rec, host.data() + per * (size_t)rec, per * sizeof(rt_f4), hipMemcpyHostToDevice));
@@ -1926,7 +1971,7 @@ int rt_trace_primary(RtScene* s, const RtCamera* cam, const RtRenderParams* p, i
             if (s->shade_fused) {
                 dim3 lgrid((unsigned)std::max(RT_SHARDS, s->n_cu / RT_SHARDS / RT_SHARDS * RT_SHARDS), RT_SHARDS);
                 hipLaunchKernelGGL((k_shade_lds<true, true>), lgrid, dim3(1024), (size_t)s->shade_lds_bytes, 0, s->view, s->shade_plan, fr, 1, cap, cin,
-                                   ws.counts + 2 * row_words, ws.counts, ws.qa[0], ws.qb[0], ws.qc[0], ws.hits[1], ws.qa[1], ws.qb[1], ws.qc[1], ws.contrib, nullptr, nullptr, nullptr);
+                                   ws.counts + 2 * row_words, ws.counts, ws.qa[0], ws.qb[0], ws.qc[0], ws.hits[1], ws.qa[1], ws.qb[1], ws.qc[1], ws.contrib, nullptr, nullptr, nullptr, RtLocalSurfs());
             } else
                 launch_trace(s, ws, false, 0, cap, cin, ws.counts + (size_t)(ws.rows + 1) * row_words, ws.qa[0], ws.qb[0], ws.hits[1]);
             dim3 fgrid((unsigned)std::max<size_t>(1, std::min<size_t>((n / RT_SHARDS + RT_BLOCK - 1) / RT_BLOCK + 1, 4096)), RT_SHARDS);

@@ -113,7 +113,7 @@ def test_synthetic_sphere_field_matches_oracle(gpu_required):
 
 
 @pytest.mark.parametrize("env", [{"RT_TRACE_WIDE_STACK": "1"}, {"RT_TRACE_BLOCK": "256"}, {"RT_SHADE_LDS": "0"}, {"RT_SHADE_FUSED": "0"},
-                                 {"RT_TRACE_BVH4": "1", "RT_SHADE_FUSED": "0"}, {"RT_SHADE_FLAT": "0"}, {"RT_LOCAL_MEDIA": "0"},
+                                 {"RT_TRACE_BVH4": "1", "RT_SHADE_FUSED": "0"}, {"RT_SHADE_FLAT": "0"}, {"RT_LOCAL_MEDIA": "0"}, {"RT_LOCAL_SURFACES": "1"},
                                  {"RT_TRACE_STACK_LDS": "6"}, {"RT_TRACE_STACK_LDS": "3", "RT_TRACE_BVH4": "1", "RT_SHADE_FUSED": "0"}])
 @pytest.mark.parametrize("name", ["cornell.yml", "final_scene.yml", "showcase.yml", "rectangle.yml", "orig_img.yml", "cornell_box.yml", "two_spheres.yml"])
 def test_kernel_variants_agree(gpu_required, name, env):

@@ -468,7 +468,13 @@ def test_walks_inside_a_medium_skip_the_tree_search_exactly(gpu_required):
         s0, off, st_off, _ = render("0", **kw)
         assert st_on.rays == st_off.rays and list(st_on.rays_per_bounce) == list(st_off.rays_per_bounce) and np.array_equal(on, off), kw
         assert st_on.rays > 3 * W * H * spp                              # the walks are there: paths are long
-        s0.close(); s1.close()
+        os.environ["RT_LOCAL_SURFACES"] = "1"                            # also settle rays that start on a surface wholly inside the ball
+        try:
+            s2, both, st_both, _ = render("1", **kw)
+        finally:
+            os.environ.pop("RT_LOCAL_SURFACES", None)
+        assert st_both.rays == st_off.rays and np.array_equal(both, off), kw
+        s0.close(); s1.close(); s2.close()
     ob = OracleBuilder()
     ow, _ = _walk_scene(ob)
     ob.set_world(ow)
