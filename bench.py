@@ -101,14 +101,15 @@ def per_ray_work(st):
     n_shade = sum(shades.values())
     tests = dict(node=w[0], wide_node=w[15], sphere=w[1], msphere=w[2], rect=w[3], instance=w[4], box=w[7])
     trace_flops = sum(tests[k] * FLOPS[k] for k in tests)
-    trace_bytes = rays * (TRACE_BYTES["ray"] + TRACE_BYTES["hit"]) + sum(tests[k] * TRACE_BYTES[k] for k in tests)
+    traced = rays - float(st.rays_settled)     # k_trace reads and writes records only for the rays it searches for
+    trace_bytes = traced * (TRACE_BYTES["ray"] + TRACE_BYTES["hit"]) + sum(tests[k] * TRACE_BYTES[k] for k in tests)
     flops = (trace_flops + w[5] * FLOPS["medium"] + paths * FLOPS["raygen"] + n_shade * FLOPS["finalize"] +
              sum(shades[k] * FLOPS[k] for k in shades) + w[13] * FLOPS["noise"] + w[14] * FLOPS["checker"])
     byts = (trace_bytes + rays * SHADE_BYTES["ray_in"] + n_shade * (SHADE_BYTES["ray_out"] + SHADE_BYTES["material"]) +
             paths * (48 + SHADE_BYTES["contrib"] * 2))
     counts = dict(nodes=w[0] / rays, wide_nodes=w[15] / rays, sphere_tests=w[1] / rays, msphere_tests=w[2] / rays, rect_tests=w[3] / rays,
                   box_tests=w[7] / rays, instance_entries=w[4] / rays, medium_tests=w[5] / rays, miss_fraction=w[6] / rays, noise_shades=w[13] / rays,
-                  rays_per_path=rays / paths)
+                  rays_per_path=rays / paths, settled_without_the_tree=float(st.rays_settled) / rays)
     return trace_flops / rays, trace_bytes / rays, flops / rays, byts / rays, counts
 
 
@@ -178,7 +179,7 @@ def main():
                                 background=tuple(getattr(cfg, "background", (0.0, 0.0, 0.0))), flags=flags)
 
     def run_steps(scenes, cam, cfg, spp, steps, first_step, accum, stream_ptr):
-        rays = kernel_ms = launches = trace_ms = trace_launches = 0
+        rays = kernel_ms = launches = trace_ms = trace_launches = settled = 0
         seen = (0, 0)
         for k in range(steps):
             if inprocess:          # one rt_render_multi call: the samples of all GPUs of this step, sharded inside the library
@@ -192,8 +193,8 @@ def main():
                 st = scenes[0].render_device(cam, params(cfg, spp, offset, rt.RT_FLAG_TIME_TRACE), accum.data_ptr(), None, stream_ptr)
                 reduce_accumulators(accum, 0)
             rays += int(st.rays); kernel_ms += st.kernel_ms_extend; launches += int(st.extend_launches)
-            trace_ms += st.kernel_ms_trace; trace_launches += int(st.trace_launches)
-        return rays, kernel_ms, launches, trace_ms, trace_launches, seen
+            trace_ms += st.kernel_ms_trace; trace_launches += int(st.trace_launches); settled += int(st.rays_settled)
+        return rays, kernel_ms, launches, trace_ms, trace_launches, seen, settled
 
     def timed(config_name, steps, warmup, spp=None):
         spp = spp or args.spp_per_step
@@ -206,7 +207,7 @@ def main():
         run_steps(scenes, cam, cfg, spp, warmup, 0, accum, stream_ptr)
         barrier()
         t0 = time.perf_counter()
-        rays, kernel_ms, launches, trace_ms, trace_launches, seen = run_steps(scenes, cam, cfg, spp, steps, warmup, accum, stream_ptr)
+        rays, kernel_ms, launches, trace_ms, trace_launches, seen, settled = run_steps(scenes, cam, cfg, spp, steps, warmup, accum, stream_ptr)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -219,7 +220,7 @@ def main():
         mean = float(accum.mean()) / (spp * n_units)               # rank 0: image mean of the last step (sanity only)
         # rays0 / kernel times are those of the GPU(s) this process drove; per_gpu divides them for the per-launch figures
         return dict(cfg=cfg, cam=cam, scenes=scenes, dt=dt, total_rays=total_rays, rays0=rays, kernel_ms=kernel_ms, launches=launches, trace_ms=trace_ms,
-                    trace_launches=trace_launches, mean=mean, spp=spp, seen=seen, name=config_name)
+                    trace_launches=trace_launches, mean=mean, spp=spp, seen=seen, name=config_name, settled=settled)
 
     def close(run):
         for s in run["scenes"]:
@@ -275,7 +276,8 @@ def main():
             t_s = b_s                                             # ... which is then the dominant (only) bounce kernel
         # in-process runs sum rays and launches over the handles and report the slowest GPU's kernel time: per-GPU figures below
         n_tr = max(run["launches"] if fused else run["trace_launches"], 1) / n_handles
-        rays_gpu = rays0 / n_handles
+        # the rays the kernel handled: k_trace does not see the rays whose closest hit the shading kernel settled (RtStats.rays_settled)
+        rays_gpu = (rays0 if fused else rays0 - run["settled"]) / n_handles
         hbm_bytes = FUSED_BYTES if fused else TRACE_BYTES["ray"] + TRACE_BYTES["hit"]
         gbs = hbm_bytes * rays_gpu / t_s / 1e9
         kname = ("k_shade_lds<fused> (closest hit + shading in one kernel; k_trace is not run for this scene)" if fused else
@@ -283,7 +285,8 @@ def main():
         r = {"kernel": kname, "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
              "bytes_per_ray": hbm_bytes, "rays_per_launch": rays_gpu / n_tr, "bytes_per_launch": hbm_bytes * rays_gpu / n_tr,
              "avg_launch_ms": t_s * 1e3 / n_tr, "launches": n_tr, "timing": "HIP event pairs on the render stream, inside this run",
-             "share_of_bounce_time": t_s / b_s, "mrays_per_s_in_kernel": rays_gpu / t_s / 1e6}
+             "share_of_bounce_time": t_s / b_s, "mrays_per_s_in_kernel": rays_gpu / t_s / 1e6,
+             "rays_settled_by_the_shading_kernel_frac": run["settled"] / max(rays0, 1)}
         return r, fused, t_s, b_s
 
     # ---- the CPU baseline runs on host threads beside the first secondary GPU leg (the oracle call releases the GIL), so that the

@@ -196,6 +196,11 @@ typedef struct RtStats {
     /* rt_render_multi only: distinct GPUs that rendered; ranks of the RCCL communicator that carried the reduce (0: no reduce was
      * needed -- one GPU, or pixel sharding); 1 when the pixels were sharded (RT_FLAG_TILES), 0 when the samples were */
     int32_t multi_gpus, multi_comm_ranks, multi_tiles, reserved_;
+    /* Of `rays`, those whose closest-hit search (src/lib.rs:63) was settled without the tree: steps of a walk inside a constant
+     * medium whose boundary encloses a known handful of surfaces are tested against just those, by the shading kernel that makes
+     * the ray (same tests, same operands, same result).  They are ray segments like the others; the closest-hit kernel traced
+     * rays - rays_settled. */
+    uint64_t rays_settled;
 } RtStats;
 
 /* Renders `spp` samples of every pixel and ADDS the per-pixel colour sums (src/main.rs:585-589) to

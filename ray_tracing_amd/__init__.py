@@ -64,7 +64,8 @@ class RtStats(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("rays_per_bounce", C.c_uint64 * 64),
                 ("seconds", C.c_double), ("kernel_ms_extend", C.c_double), ("extend_launches", C.c_uint64),
                 ("passes", C.c_int32), ("work", C.c_uint64 * 16), ("kernel_ms_trace", C.c_double), ("trace_launches", C.c_uint64),
-                ("multi_gpus", C.c_int32), ("multi_comm_ranks", C.c_int32), ("multi_tiles", C.c_int32), ("reserved_", C.c_int32)]
+                ("multi_gpus", C.c_int32), ("multi_comm_ranks", C.c_int32), ("multi_tiles", C.c_int32), ("reserved_", C.c_int32),
+                ("rays_settled", C.c_uint64)]
 
 
 # name -> (restype, argtypes); every symbol include/rt_hip.h declares

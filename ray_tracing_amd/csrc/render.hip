@@ -786,6 +786,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_fold_counts(const uint32_t* counts
         if (back && row > 0) sum += back[((size_t)row * RT_SHARDS + sh) * RT_COUNT_STRIDE];   // both parts of a region hold rays of the bounce
     }
     folded[row] = sum;
+    if (row == 0) {   // one more word behind the rows: the rays of all bounces that sat in the back parts (settled by the shading kernel)
+        unsigned long long settled = 0;
+        if (back) for (int r = 1; r < rows; ++r) for (int sh = 0; sh < RT_SHARDS; ++sh) settled += back[((size_t)r * RT_SHARDS + sh) * RT_COUNT_STRIDE];
+        folded[rows] = settled;
+    }
 }
 
 // Parity hook: closest hit of one sample per pixel.
@@ -875,7 +880,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_scatter_rays(RtSceneView sc, const
 static constexpr size_t kNaRows = RT_NOALLOC_MAX_DEPTH + 2;
 static constexpr size_t kNaCap = ((RT_NOALLOC_MAX_PATHS + RT_SHARDS - 1) / RT_SHARDS + (size_t)1024 * (RT_SHARDS + 2) + RT_BLOCK - 1) / RT_BLOCK * RT_BLOCK;
 static constexpr size_t kNaCountsBytes = 2 * kNaRows * RT_SHARDS * RT_COUNT_STRIDE * sizeof(uint32_t);
-static constexpr size_t kNaFoldedBytes = (kNaRows * sizeof(unsigned long long) + 255) / 256 * 256;
+static constexpr size_t kNaFoldedBytes = ((kNaRows + 1) * sizeof(unsigned long long) + 255) / 256 * 256;
 static constexpr size_t kNaContribBytes = (size_t)RT_NOALLOC_MAX_PATHS * sizeof(rt_f4);
 static constexpr size_t kNaStreamBytes = kNaCap * RT_SHARDS * sizeof(rt_f4);     // one queue stream, or the hit stream
 static constexpr size_t kNaScratchBytes = kNaCountsBytes + kNaFoldedBytes + kNaContribBytes + 7 * kNaStreamBytes;   // 64 MiB
@@ -1176,7 +1181,7 @@ static int ensure_workspace(RtScene* s, Workspace& w, size_t n_paths) {
     if (!w.counts) {
         w.rows = RT_MAX_BOUNCES + 2;
         HIP_TRY(hipMalloc((void**)&w.counts, (size_t)3 * w.rows * RT_SHARDS * RT_COUNT_STRIDE * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc((void**)&w.folded, (size_t)w.rows * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc((void**)&w.folded, (size_t)(w.rows + 1) * sizeof(unsigned long long)));
     }
     if (!w.work) { HIP_TRY(hipMalloc((void**)&w.work, 32 * sizeof(unsigned long long))); }
     if (!s->ev0) { HIP_TRY(hipEventCreate(&s->ev0)); HIP_TRY(hipEventCreate(&s->ev1)); }
@@ -1405,7 +1410,7 @@ int rt_scene_info(const RtScene* s, RtSceneInfo* out) {
 }  // extern "C"
 
 // The passes of one render call on workspace `ws`: samples [sample_offset, sample_offset + spp) of every pixel, `chunk_max`
-// samples per pass.  Everything is enqueued on `st`.  h_folded (max_depth + 2 words, or null) receives the per-bounce ray
+// samples per pass.  Everything is enqueued on `st`.  h_folded (max_depth + 3 words, or null) receives the per-bounce ray
 // counts of each pass: the stream is then synchronised once per pass and `local` is complete on return; with null nothing is
 // read back and the call returns with the work still in flight.  Events are recorded only when the scene's are given.
 static int render_passes(RtScene* s, const Workspace& ws, const RtCamera* cam, const RtRenderParams* p, int chunk_max, float* d_accum, float* sq,
@@ -1495,7 +1500,7 @@ static int render_passes(RtScene* s, const Workspace& ws, const RtCamera* cam, c
         if (!h_folded) continue;
         const int rows = p->max_depth + 2;
         hipLaunchKernelGGL(k_fold_counts, dim3((rows + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, ws.counts, back, rows, ws.folded);
-        HIP_TRY(hipMemcpyAsync(h_folded, ws.folded, (size_t)rows * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_folded, ws.folded, (size_t)(rows + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (back && std::getenv("RT_DEBUG_COUNTS")) {   // developer output: per bounce, the rays in the front and in the back parts of the regions
             std::vector<uint32_t> hc((size_t)3 * ws.rows * row_words);
@@ -1525,6 +1530,7 @@ static int render_passes(RtScene* s, const Workspace& ws, const RtCamera* cam, c
             local.rays += h_folded[b];
             if (b <= 64) local.rays_per_bounce[b - 1] += h_folded[b];
         }
+        local.rays_settled += h_folded[rows];
     }
     if (instrumented && h_folded) {
         unsigned long long w[16];
@@ -1574,7 +1580,7 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     if (rc) return rc;
     RtStats local; std::memset(&local, 0, sizeof(local));
     local.paths = (uint64_t)set_pixels(p) * (uint64_t)p->spp;
-    std::vector<unsigned long long> h_folded((size_t)p->max_depth + 2);
+    std::vector<unsigned long long> h_folded((size_t)p->max_depth + 3);
     float* sq = (p->flags & RT_FLAG_SUMSQ) ? d_accum_sq : nullptr;
     rc = render_passes(s, pool->ws, cam, p, chunk_max, d_accum, sq, st, true, h_folded.data(), local);
     if (rc) return rc;
@@ -1620,7 +1626,7 @@ int rt_render_device_noalloc(RtScene* s, const RtCamera* cam, const RtRenderPara
     const Workspace ws = static_workspace(s->static_scratch);
     RtStats local; std::memset(&local, 0, sizeof(local));
     local.paths = (uint64_t)set_pixels(p) * (uint64_t)p->spp;
-    unsigned long long h_folded[RT_NOALLOC_MAX_DEPTH + 2];
+    unsigned long long h_folded[RT_NOALLOC_MAX_DEPTH + 3];
     float* sq = (p->flags & RT_FLAG_SUMSQ) ? d_accum_sq : nullptr;
     rc = render_passes(s, ws, cam, p, chunk_max, d_accum, sq, st, false, stats ? h_folded : nullptr, local);
     if (rc) return rc;
@@ -1917,7 +1923,7 @@ int rt_render_multi(RtScene* const* scenes, int32_t n_scenes, const RtCamera* ca
     if (stats) {
         RtStats tot; std::memset(&tot, 0, sizeof(tot));
         for (int i = 0; i < n; ++i) {
-            tot.rays += st[i].rays; tot.paths += st[i].paths; tot.passes += st[i].passes;
+            tot.rays += st[i].rays; tot.paths += st[i].paths; tot.passes += st[i].passes; tot.rays_settled += st[i].rays_settled;
             tot.extend_launches += st[i].extend_launches; tot.trace_launches += st[i].trace_launches;
             tot.kernel_ms_extend = std::max(tot.kernel_ms_extend, st[i].kernel_ms_extend);
             tot.kernel_ms_trace = std::max(tot.kernel_ms_trace, st[i].kernel_ms_trace);
