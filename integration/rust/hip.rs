@@ -21,12 +21,15 @@ pub struct RtCamera {                      // arguments of Camera::new, cameras.
 pub struct RtRenderParams {
     pub width: i32, pub height: i32, pub spp: i32, pub sample_offset: i32, pub max_depth: i32,
     pub background: [f32; 3], pub seed: u64, pub paths_per_pass: i32, pub flags: i32,
+    pub tile: [i32; 4], pub stripe: [i32; 3], pub reserved_: i32,   // the pixels rendered; all zero = the whole image
 }
 #[repr(C)]
 pub struct RtStats {
     pub rays: u64, pub paths: u64, pub rays_per_bounce: [u64; 64], pub seconds: f64,
     pub kernel_ms_extend: f64, pub extend_launches: u64, pub passes: i32, pub work: [u64; 16],
     pub kernel_ms_trace: f64, pub trace_launches: u64,
+    pub multi_gpus: i32, pub multi_comm_ranks: i32, pub multi_tiles: i32, pub reserved_: i32,
+    pub rays_settled: u64,
 }
 
 extern "C" {
@@ -63,6 +66,12 @@ extern "C" {
     pub fn rt_trace_primary(s: *mut RtScene, cam: *const RtCamera, p: *const RtRenderParams, sample: i32,
                             object_id: *mut i32, t: *mut f32, normal: *mut f32, front_face: *mut i32, uv: *mut f32) -> c_int;
     pub fn rt_tonemap_u8(accum_rgb: *const f32, n_pixels: i32, spp: i32, rgb: *mut u8) -> c_int;
+    // several GPUs inside one process (src/main.rs:585-589 lifted across GPUs); see include/rt_hip.h
+    pub fn rt_render_multi(scenes: *const *mut RtScene, n_scenes: i32, cam: *const RtCamera, p: *const RtRenderParams, accum_rgb: *mut f32,
+                           accum_sq: *mut f32, stats: *mut RtStats) -> c_int;
+    pub fn rt_shard_samples(total_spp: i32, n_shards: i32, shard: i32, first: *mut i32, count: *mut i32) -> c_int;
+    pub fn rt_shard_tiles(p: *mut RtRenderParams, n_shards: i32, shard: i32, n_pixels: *mut i64) -> c_int;
+    pub fn rt_multi_shutdown() -> c_int;
 }
 
 /// Negative status -> Err(message of rt_last_error()).  Handles (RtTex / RtMat / RtObj) follow the same rule.

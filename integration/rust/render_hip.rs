@@ -25,7 +25,7 @@ pub fn render_on_gpu(world: &HittableList, cam: &CameraConfig, width: u32, heigh
         };
         let p = RtRenderParams { width: width as i32, height: height as i32, spp: spp as i32, sample_offset: 0,
                                  max_depth: max_depth as i32, background: opt.background, seed: opt.seed,
-                                 paths_per_pass: 0, flags: 0 };
+                                 paths_per_pass: 0, flags: 0, tile: [0; 4], stripe: [0; 3], reserved_: 0 };
         let mut accum = vec![0f32; (width * height * 3) as usize];
         let rc = check(hip::rt_render(scene, &camera, &p, accum.as_mut_ptr(), std::ptr::null_mut(), std::ptr::null_mut()));
         hip::rt_scene_destroy(scene);
