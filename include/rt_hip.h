@@ -212,10 +212,11 @@ int rt_render(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* a
 int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* d_accum_rgb, float* d_accum_sq,
                      void* hip_stream, RtStats* stats);
 
-/* The wavefront workspace (ray queues, hit records, contribution slots: 128 bytes per path of a pass, 34 GB for the default pass of
+/* The wavefront workspace (ray queues, hit records, contribution slots: 144 bytes per path of a pass, 38 GB for the default pass of
  * 2^28 paths) belongs to the GPU, not to a scene: all scene handles on one GPU share it, it only grows, and render calls on one GPU
- * take turns on it (calls on different GPUs run side by side).  rt_release_workspace frees it, e.g. before handing the GPU's memory to
- * another library; the next render allocates it again.  No counterpart in the reference. */
+ * take turns on it (calls on different GPUs run side by side).  It is freed when the last scene handle on the GPU is destroyed, or by
+ * rt_release_workspace, e.g. before handing the GPU's memory to another library while scenes stay alive; the next render allocates it
+ * again.  No counterpart in the reference. */
 int rt_release_workspace(int device);
 
 /* rt_render_device for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
@@ -223,7 +224,9 @@ int rt_release_workspace(int device);
  * of a pass live in a static 64 MiB device array that every GPU the library runs on holds until the process ends, so the call
  * makes no hipMalloc / hipFree and creates no events.  Limits: width * height <= 262144 (paths of one pass), max_depth <= 126,
  * flags = 0 or RT_FLAG_SUMSQ; anything beyond is RT_ERR_INVALID.  With stats == NULL nothing is read back and the call returns with the work
- * enqueued on `hip_stream`; with stats the stream is synchronised once per pass.  All calls on one GPU share that GPU's array: calls
+ * enqueued on `hip_stream` (a call can then be captured into a HIP graph: tests/test_zz_no_alloc.py); with stats the stream is synchronised
+ * once per pass.  The queue-overflow check (RT_ERR_INTERNAL) needs that read-back: a caller that passes NULL trusts the capacity bound, which
+ * holds by construction for every pass size the entry point accepts.  All calls on one GPU share that GPU's array: calls
  * that overlap on one GPU race (serialise them on one stream).  Results are bit-identical to rt_render_device with
  * paths_per_pass = 262144. */
 int rt_render_device_noalloc(RtScene* s, const RtCamera* cam, const RtRenderParams* p, float* d_accum_rgb, float* d_accum_sq,

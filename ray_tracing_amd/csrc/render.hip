@@ -890,7 +890,7 @@ static __device__ __align__(256) unsigned char g_noalloc_scratch[kNaScratchBytes
 // ------------------------------------------------------------------ host side
 // Device memory of one wavefront pass: the two ray queues (three float4 streams each), the hit stream, one contribution slot
 // per path and the counters.  Every GPU has ONE grow-only workspace (hipMalloc) that all scene handles on it share -- a pass of
-// 2^28 paths needs 34 GB, which no caller should pay once per scene -- and rt_render_device_noalloc carves a fixed one out of a
+// 2^28 paths needs 38 GB, which no caller should pay once per scene -- and rt_render_device_noalloc carves a fixed one out of a
 // static device array instead.
 struct Workspace {
     size_t paths = 0, cap = 0;             // paths it was sized for; slots per queue region
@@ -1392,7 +1392,7 @@ void rt_scene_destroy(RtScene* s) {
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     for (hipEvent_t e : s->ev_trace) (void)hipEventDestroy(e);
-    // the last handle on a GPU takes the shared workspace with it (34 GB for a default pass: a caller that closes its scenes and
+    // the last handle on a GPU takes the shared workspace with it (38 GB for a default pass: a caller that closes its scenes and
     // hands the GPU to another library must get the memory back)
     bool last = false;
     if (s->counted) { DeviceWorkspace* d = device_workspace(s->device); std::lock_guard<std::mutex> lock(g_pool_mutex); last = --d->handles == 0; }
@@ -1561,7 +1561,7 @@ int rt_render_device(RtScene* s, const RtCamera* cam, const RtRenderParams* p, f
     HIP_TRY(hipSetDevice(s->device));
     auto t_begin = std::chrono::steady_clock::now();
     const size_t n_pixels = std::max<size_t>(1, set_pixels(p));
-    // Default pass: up to 2^28 paths in flight (34 GB of queues, hit and contribution slots on a 288 GB part).  Late
+    // Default pass: up to 2^28 paths in flight (38 GB of queues, hit and contribution slots on a 288 GB part).  Late
     // bounces hold few rays per launch and run below the bulk rate; the more paths share a pass, the less that costs
     // (final_scene.yml: +10 % from 2^26 to 2^28).
     size_t target = p->paths_per_pass > 0 ? (size_t)p->paths_per_pass : ((size_t)1 << 28);

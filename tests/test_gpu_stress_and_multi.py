@@ -381,7 +381,11 @@ def test_scenes_on_one_gpu_share_one_workspace(gpu_required):
     assert torch.cuda.mem_get_info(0)[0] - before > 100 << 20                    # 400 * 400 * 8 paths * 128 B and the region slack
     again, _, _ = a.render(cam_a, pa)                                            # allocated again on demand
     assert np.array_equal(again, want_a)
-    a.close(); b.close()
+    # the last handle on the GPU takes the workspace with it: a caller that closes its scenes gets the memory back
+    a.close()
+    held = torch.cuda.mem_get_info(0)[0]
+    b.close()
+    assert torch.cuda.mem_get_info(0)[0] - held > 100 << 20
 
 
 def _hip_rank(rank, world_size, port, out_path):
