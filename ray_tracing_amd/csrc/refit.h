@@ -138,10 +138,14 @@ RT_HD void rt_refit_node(const RtSceneView& sc, rt_f4* nodes, int i, int pass, i
 
 // ---- 4-wide quantised node: encoding of n <= 4 children (boxes + codes) into the four records described in wide_bvh.cpp.
 RT_HD void rt_wide_encode(const RtBox6* c, const int32_t* code_in, int n, rt_f4 w[4]) {
+    // (every loop over children or axes has a constant trip count and is unrolled: indexed by a variable, the arrays would live in
+    // scratch memory on the GPU)
     float org[3]; double step[3];
+#pragma unroll
     for (int a = 0; a < 3; ++a) {
         float lo = rt_inf(), hi = -rt_inf();
-        for (int k = 0; k < n; ++k) { lo = fminf(lo, c[k].lo[a]); hi = fmaxf(hi, c[k].hi[a]); }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < n) { lo = fminf(lo, c[k].lo[a]); hi = fmaxf(hi, c[k].hi[a]); }
         if (n == 0) { lo = hi = 0.0f; }
         org[a] = lo;
         double ext = (double)hi - (double)lo;
@@ -152,12 +156,15 @@ RT_HD void rt_wide_encode(const RtBox6* c, const int32_t* code_in, int n, rt_f4 
     }
     uint32_t q[6] = {0, 0, 0, 0, 0, 0};                     // lo.x lo.y lo.z hi.x hi.y hi.z, child k in byte k
     int32_t code[4];
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (k >= n) {                                       // absent: an inverted box and a code no traversal enters
+#pragma unroll
             for (int a = 0; a < 3; ++a) q[a] |= 255u << (8 * k);
             code[k] = RT_EMPTY_STACK;
             continue;
         }
+#pragma unroll
         for (int a = 0; a < 3; ++a) {
             double lo = floor(((double)c[k].lo[a] - (double)org[a]) / step[a]);
             double hi = ceil(((double)c[k].hi[a] - (double)org[a]) / step[a]);
@@ -177,14 +184,15 @@ RT_HD void rt_wide_refit_node(const rt_f4* nodes, const int32_t* src, rt_f4* wno
     rt_f4* w = wnodes + 4 * (size_t)i;
     rt_f4 w2 = w[2], w3 = w[3];
     int32_t old_code[4] = {f2i(w2.z), f2i(w2.w), f2i(w3.x), f2i(w3.y)};
-    RtBox6 c[4]; int32_t code[4]; int n = 0;
-    for (int k = 0; k < 4; ++k) {
+    RtBox6 c[4]; int n = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                                // present children are the first n slots (wide_bvh.cpp), so slot k stays slot k
         int32_t s = src[4 * (size_t)i + k];
         if (s < 0) continue;
         RtBox6 l, r; rt_node_boxes(nodes, s >> 1, l, r);
-        c[n] = (s & 1) ? r : l; code[n] = old_code[k]; ++n;      // present children are the first n slots, in order
+        c[k] = (s & 1) ? r : l; n = k + 1;
     }
     rt_f4 out[4];
-    rt_wide_encode(c, code, n, out);
+    rt_wide_encode(c, old_code, n, out);
     w[0] = out[0]; w[1] = out[1]; w[2] = out[2]; w[3] = out[3];
 }

@@ -412,7 +412,8 @@ __device__ __forceinline__ void shade_ray(const RtSceneView& sc, const Tab& tab,
                     uint32_t from = RT_HIT_NONE;                       // the surface the ray starts on, as the tree search is told (k_trace's src)
                     if (RT_HIT_KIND(hit.code) == RT_KIND_MEDIUM) m = (int)RT_HIT_INDEX(hit.code);
                     else if (hit.inst < 0) {
-                        for (int k = 0; k < ls.n; ++k) if ((hit.code & ls.mask[k]) == ls.code[k]) m = ls.medium[k];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (k < ls.n && (hit.code & ls.mask[k]) == ls.code[k]) m = ls.medium[k];   // unrolled: indexed by a variable, the arrays would be copied to scratch memory
                         from = hit.code;
                     }
                     const rt_f4 m5 = msrc.get(max(m, 0), 5);

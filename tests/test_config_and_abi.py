@@ -257,3 +257,23 @@ def test_extended_list_schema(tmp_path):
         with pytest.raises(rt.RtError) as e:
             rt.load_config(str(path))
         assert e.value.code == -7 and "Could not read values." in str(e.value) and msg in str(e.value), (msg, str(e.value))
+
+
+def test_no_kernel_uses_scratch_memory():
+    """The library build records what the compiler reports per kernel (ray_tracing_amd/kernel_resources.json).  No kernel may spill
+    registers or index a private array (both end up in scratch memory, a round trip to HBM per access), and the kernels that run one
+    1024-thread block per CU must fit the 128 registers that leaves each lane."""
+    import json
+    from ray_tracing_amd import build
+    assert os.path.exists(build.RESOURCES), "run python -m ray_tracing_amd.build"
+    assert os.path.getmtime(build.RESOURCES) >= os.path.getmtime(build.LIB) - 120
+    res = json.load(open(build.RESOURCES))
+    names = " ".join(res)
+    for k in ("k_raygen", "k_trace<", "k_shade<", "k_shade_lds<", "k_accumulate", "k_refit_pass", "k_lbvh_nodes"):
+        assert k in names, k
+    for name, r in res.items():
+        if not name.startswith("k_"):      # rocPRIM's sort kernels (device BVH build) are the library's business
+            continue
+        assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs Spill"] == 0 and r["Dynamic Stack"] == "False", (name, r)
+        if name.startswith("k_shade_lds<") or ("k_trace<" in name and ", 1024," in name):
+            assert r["VGPRs"] + r["AGPRs"] <= 128, (name, r)

@@ -128,7 +128,7 @@ def test_kernel_variants_agree(gpu_required, name, env):
         scene = rt.Scene(b, b.scene_from_config(os.path.join(CONFIGS, name), SCENE_SEED), 0)
         img, _, st = scene.render(cam, p)
         scene.close()
-        return img, st.rays
+        return img, (st.rays, tuple(st.rays_per_bounce))
     want, rays = render()
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
