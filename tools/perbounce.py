@@ -8,4 +8,4 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 tr, sh = tr[-n:], sh[-n:]
 print("trace us:", " ".join("%.0f" % d(r) for r in tr))
 print("shade us:", " ".join("%.0f" % d(r) for r in sh))
-print("trace sum %.0f  shade sum %.0f" % (sum(map(d, tr)), sum(map(d, sh))))
+print("trace sum %.0f  shade sum %.0f   launches 11..: trace %.0f  shade %.0f" % (sum(map(d, tr)), sum(map(d, sh)), sum(map(d, tr[10:])), sum(map(d, sh[10:]))))
