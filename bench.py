@@ -41,7 +41,6 @@ FLOPS = dict(node=2 * 24, wide_node=4 * 24, sphere=26, msphere=35, rect=12, box=
 TRACE_BYTES = dict(ray=32, hit=16, node=64, wide_node=64, sphere=16, msphere=48, rect=32, box=32, instance=32)
 # the rest of a bounce (k_shade): ray 48 B + hit 16 B in, scattered ray 48 B out, contribution slot 16 B
 SHADE_BYTES = dict(ray_in=64, ray_out=48, contrib=16, material=32)
-FUSED_BYTES = SHADE_BYTES["ray_in"] - 16 + SHADE_BYTES["ray_out"] + SHADE_BYTES["contrib"]   # fused kernel: ray in (no hit record), ray out, contribution
 
 
 def parse_args():
@@ -179,7 +178,7 @@ def main():
                                 background=tuple(getattr(cfg, "background", (0.0, 0.0, 0.0))), flags=flags)
 
     def run_steps(scenes, cam, cfg, spp, steps, first_step, accum, stream_ptr):
-        rays = kernel_ms = launches = trace_ms = trace_launches = settled = 0
+        rays = kernel_ms = launches = trace_ms = trace_launches = settled = first = paths = 0
         seen = (0, 0)
         for k in range(steps):
             if inprocess:          # one rt_render_multi call: the samples of all GPUs of this step, sharded inside the library
@@ -194,7 +193,8 @@ def main():
                 reduce_accumulators(accum, 0)
             rays += int(st.rays); kernel_ms += st.kernel_ms_extend; launches += int(st.extend_launches)
             trace_ms += st.kernel_ms_trace; trace_launches += int(st.trace_launches); settled += int(st.rays_settled)
-        return rays, kernel_ms, launches, trace_ms, trace_launches, seen, settled
+            first += int(st.rays_per_bounce[0]); paths += int(st.paths)
+        return rays, kernel_ms, launches, trace_ms, trace_launches, seen, settled, first, paths
 
     def timed(config_name, steps, warmup, spp=None):
         spp = spp or args.spp_per_step
@@ -207,7 +207,7 @@ def main():
         run_steps(scenes, cam, cfg, spp, warmup, 0, accum, stream_ptr)
         barrier()
         t0 = time.perf_counter()
-        rays, kernel_ms, launches, trace_ms, trace_launches, seen, settled = run_steps(scenes, cam, cfg, spp, steps, warmup, accum, stream_ptr)
+        rays, kernel_ms, launches, trace_ms, trace_launches, seen, settled, first, paths = run_steps(scenes, cam, cfg, spp, steps, warmup, accum, stream_ptr)
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -220,7 +220,7 @@ def main():
         mean = float(accum.mean()) / (spp * n_units)               # rank 0: image mean of the last step (sanity only)
         # rays0 / kernel times are those of the GPU(s) this process drove; per_gpu divides them for the per-launch figures
         return dict(cfg=cfg, cam=cam, scenes=scenes, dt=dt, total_rays=total_rays, rays0=rays, kernel_ms=kernel_ms, launches=launches, trace_ms=trace_ms,
-                    trace_launches=trace_launches, mean=mean, spp=spp, seen=seen, name=config_name, settled=settled)
+                    trace_launches=trace_launches, mean=mean, spp=spp, seen=seen, name=config_name, settled=settled, first=first, paths=paths)
 
     def close(run):
         for s in run["scenes"]:
@@ -278,7 +278,14 @@ def main():
         n_tr = max(run["launches"] if fused else run["trace_launches"], 1) / n_handles
         # the rays the kernel handled: k_trace does not see the rays whose closest hit the shading kernel settled (RtStats.rays_settled)
         rays_gpu = (rays0 if fused else rays0 - run["settled"]) / n_handles
-        hbm_bytes = FUSED_BYTES if fused else TRACE_BYTES["ray"] + TRACE_BYTES["hit"]
+        if fused:
+            # What the fused kernel moves, from the run's own counts: a camera ray is read as two records, every later ray as three;
+            # every ray but a camera ray was written as three records by the launch before; a path's contribution slot is written once.
+            later = rays0 - run["first"]
+            hbm_bytes = (32.0 * run["first"] + (SHADE_BYTES["ray_in"] - 16) * later + SHADE_BYTES["ray_out"] * later +
+                         SHADE_BYTES["contrib"] * run["paths"]) / max(rays0, 1)
+        else:
+            hbm_bytes = TRACE_BYTES["ray"] + TRACE_BYTES["hit"]
         gbs = hbm_bytes * rays_gpu / t_s / 1e9
         kname = ("k_shade_lds<fused> (closest hit + shading in one kernel; k_trace is not run for this scene)" if fused else
                  "k_trace (closest hit of every queued ray: BVH traversal + primitive tests)")
