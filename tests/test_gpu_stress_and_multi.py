@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import ray_tracing_amd as rt
-from helpers import RENDER_SEED, SCENE_SEED, OracleBuilder, OracleCamera, config_camera, oracle_render, oracle_trace_primary, primary_agreement, scene_pair
+from helpers import CONFIGS, RENDER_SEED, SCENE_SEED, OracleBuilder, OracleCamera, config_camera, oracle_render, oracle_trace_primary, primary_agreement, scene_pair
 from parity_checks import ID_AGREEMENT, T_REL_TOL, noise_bound
 
 pytestmark = pytest.mark.gpu
@@ -498,3 +498,38 @@ def test_walks_inside_a_medium_skip_the_tree_search_exactly(gpu_required):
     assert st_m.rays == st_w.rays and np.array_equal(moved, want) and not np.array_equal(moved, img)
     assert (got_fix["id"] >= 0).any()
     scene.close(); fresh.close()
+
+
+@pytest.mark.parametrize("name", ["final_scene.yml", "cornell.yml"])
+def test_settled_rays_under_every_call_shape(gpu_required, name):
+    """The two-ended queue regions (rays the shading kernel settles go to the back part) against the one-ended form, RT_LOCAL_MEDIA=0, over
+    the shapes a call can take: depth 1 and 2 (no settled ray ever gets shaded / exactly one generation does), several passes per call,
+    passes of a few hundred paths (regions of a handful of slots, back parts included), a pixel rectangle, row bands of one shard, the
+    sum-of-squares output.  Same image, same counts, every time.  (cornell.yml's media have instanced boundaries and list no surfaces:
+    nothing is settled there, and the switch must change nothing.)"""
+    cfg, cam = config_camera(name)
+    b = rt.Builder()
+    scene = rt.Scene(b, b.scene_from_config(os.path.join(CONFIGS, name), SCENE_SEED), 0)
+    W, H = 96, 80
+    shapes = [dict(spp=3, depth=1), dict(spp=3, depth=2), dict(spp=2, depth=50), dict(spp=5, depth=50, ppp=W * H * 2), dict(spp=2, depth=50, ppp=700),
+              dict(spp=3, depth=50, tile=(8, 5, 61, 50)), dict(spp=3, depth=17, stripe=(4, 3, 1)), dict(spp=2, depth=50, tile=(3, 3, 40, 40), stripe=(8, 2, 0), ppp=3000),
+              dict(spp=2, depth=50, sumsq=True)]
+    settled_any = 0
+    for sh in shapes:
+        p = rt.render_params(W, H, sh["spp"], sh["depth"], RENDER_SEED, sample_offset=5, paths_per_pass=sh.get("ppp", 0), tile=sh.get("tile"), stripe=sh.get("stripe"))
+        res = {}
+        for local in ("1", "0"):
+            os.environ["RT_LOCAL_MEDIA"] = local
+            try:
+                img, sq, st = scene.render(cam, p, want_sumsq=bool(sh.get("sumsq")))
+            finally:
+                os.environ.pop("RT_LOCAL_MEDIA", None)
+            res[local] = (img, sq, st)
+        (i1, q1, s1), (i0, q0, s0) = res["1"], res["0"]
+        assert np.array_equal(i1, i0) and s1.rays == s0.rays and list(s1.rays_per_bounce) == list(s0.rays_per_bounce) and s1.passes == s0.passes, sh
+        assert s0.rays_settled == 0 and i1.sum() > 0, sh
+        if sh.get("sumsq"):
+            assert np.array_equal(q1, q0)
+        settled_any += int(s1.rays_settled)
+    assert (settled_any > 0) == (name == "final_scene.yml")
+    scene.close()
