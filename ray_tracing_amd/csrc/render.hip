@@ -781,17 +781,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(const rt_f4* contrib, R
 __global__ __launch_bounds__(RT_BLOCK) void k_fold_counts(const uint32_t* counts, const uint32_t* back, int rows, unsigned long long* folded) {
     int row = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (row >= rows) return;
-    unsigned long long sum = 0;
+    unsigned long long sum = 0, settled = 0;
     for (int sh = 0; sh < RT_SHARDS; ++sh) {
         sum += counts[((size_t)row * RT_SHARDS + sh) * RT_COUNT_STRIDE];
-        if (back && row > 0) sum += back[((size_t)row * RT_SHARDS + sh) * RT_COUNT_STRIDE];   // both parts of a region hold rays of the bounce
+        if (back && row > 0) settled += back[((size_t)row * RT_SHARDS + sh) * RT_COUNT_STRIDE];   // both parts of a region hold rays of the bounce
     }
-    folded[row] = sum;
-    if (row == 0) {   // one more word behind the rows: the rays of all bounces that sat in the back parts (settled by the shading kernel)
-        unsigned long long settled = 0;
-        if (back) for (int r = 1; r < rows; ++r) for (int sh = 0; sh < RT_SHARDS; ++sh) settled += back[((size_t)r * RT_SHARDS + sh) * RT_COUNT_STRIDE];
-        folded[rows] = settled;
-    }
+    folded[row] = sum + settled;
+    // one more word behind the rows (zeroed by the caller): the rays of all bounces that sat in the back parts (settled by the shading kernel)
+    if (settled) atomicAdd(folded + rows, settled);
 }
 
 // Parity hook: closest hit of one sample per pixel.
@@ -1500,6 +1497,7 @@ static int render_passes(RtScene* s, const Workspace& ws, const RtCamera* cam, c
         done += chunk;
         if (!h_folded) continue;
         const int rows = p->max_depth + 2;
+        HIP_TRY(hipMemsetAsync(ws.folded + rows, 0, sizeof(unsigned long long), st));
         hipLaunchKernelGGL(k_fold_counts, dim3((rows + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, ws.counts, back, rows, ws.folded);
         HIP_TRY(hipMemcpyAsync(h_folded, ws.folded, (size_t)(rows + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
